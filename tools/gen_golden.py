@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REFERENCE itself (this container only).
+
+The reference (``/root/reference``, read-only, never copied) is imported with one absent and unused
+dependency stubbed (``h5py``, ``model/data.py:8``; only touched under ``prep=True``).  Inputs and
+weights come from the seeded recipes in ``vfr_amd.synth`` so the fixtures hold only the reference's
+OUTPUTS plus the recipe parameters; tests regenerate the inputs from the same seeds.
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz, tokens.json
+
+Fixtures:  G1 encoders, G2 scoring + both evaluate() dicts (n=6, n=21, ragged 5/6),
+G3 generate_moments / get_iou, G4 load_video_features pooling, G5 tokeniser + WordIndexer.
+"""
+import json
+import random
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+REF = Path("/root/reference")
+sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+sys.path.insert(0, str(REF / "model"))
+
+import data as ref_data  # noqa: E402  (reference)
+import evaluate as ref_evaluate  # noqa: E402
+import evaluate_single as ref_evaluate_single  # noqa: E402
+import models as ref_models  # noqa: E402
+import utils as ref_utils  # noqa: E402
+from torch.utils.data import DataLoader  # noqa: E402
+
+from vfr_amd import synth  # noqa: E402
+
+OUT = ROOT / "tests" / "golden"
+OUT.mkdir(parents=True, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def ref_model(sd_np, feat_dim, normalize_lang=False):
+    emb = torch.from_numpy(sd_np["word_embedding.weight"])
+    m = ref_models.CALModel(2 * feat_dim + 2, pretrained_emb=emb, normalize_lang=normalize_lang)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    return m.eval()
+
+
+def make_dataset(seg, ctx, off, tokens, own, times):
+    """A reference CustomDataset filled in memory (no files): what load_video_features /
+    load_lang_features would have produced (model/data.py:183-188,196-197)."""
+    ds = ref_data.CustomDataset.__new__(ref_data.CustomDataset)
+    ds.validate = True
+    ds.video_features, ds.num_segments_info, ds.lang_features = {}, {}, {}
+    videos = [f"v{v:05d}" for v in range(len(off) - 1)]
+    for v, name in enumerate(videos):
+        n = int(off[v + 1] - off[v])
+        ds.video_features[name] = dict(segment_features=seg[off[v]:off[v + 1]].astype(np.float64),
+                                       context_features=ctx[v], num_segments=n)
+        ds.num_segments_info[name] = n
+    annots = {}
+    for q in range(tokens.shape[0]):
+        ds.lang_features[q] = torch.from_numpy(tokens[q:q + 1])
+        annots[q] = dict(video=videos[own[q]], description="", times=times[q])
+    return ds, videos, annots
+
+
+def g1_encoders():
+    feat_dim, counts = 4096, np.array([5, 6, 21, 6, 5, 21, 6, 6], np.int32)
+    seg, ctx = synth.video_features(counts, feat_dim, seed=11)
+    off = synth.clip_offsets(counts)
+    tokens = synth.query_tokens(16, seed=11)
+    tokens[0] = 0                                   # all-pad query
+    tokens[1] = 0; tokens[1, 0] = 7                 # length 1
+    tokens[2] = np.arange(1, 21)                    # full length 20
+    out = {"counts": counts, "tokens": tokens}
+    for tag, nl in (("", False), ("_normlang", True)):
+        sd = synth.model_weights(feat_dim, seed=11, normalize_lang=nl)
+        m = ref_model(sd, feat_dim, nl)
+        ds, videos, _ = make_dataset(seg, ctx, off, tokens, np.zeros(16, int), [[[0, 0]] * 4] * 16)
+        with torch.no_grad():
+            vis = torch.cat([m(ds.make_visual_features(v, 0, ds.num_segments_info[v] - 1)) for v in videos])
+            lang = m(torch.from_numpy(tokens), False, "cpu")
+        out["visual_emb" + tag] = vis.numpy()
+        out["query_emb" + tag] = lang.numpy()
+    # BERT branch (models.py:31,58-59): Linear(768 -> 100) on a pooled vector
+    rs = np.random.RandomState(5)
+    Wb = rs.uniform(-0.08, 0.08, (100, 768)).astype(np.float32)
+    bb = rs.uniform(-0.08, 0.08, 100).astype(np.float32)
+    xb = rs.randn(6, 768).astype(np.float32)
+    mb = ref_models.CALModel(2 * feat_dim + 2, pretrained_emb=None)
+    mb.lang_fc.load_state_dict({"weight": torch.from_numpy(Wb), "bias": torch.from_numpy(bb)})
+    with torch.no_grad():
+        out["bert_out"] = mb.eval()(torch.from_numpy(xb), False, "cpu", True).numpy()
+    np.savez_compressed(OUT / "g1_encoders.npz", **out)
+    print("G1", {k: v.shape for k, v in out.items()})
+
+
+def g2_scoring(tag, clips, nv=100, nq=50, feat_dim=4096):
+    counts = synth.clip_counts(nv, clips, seed=123)
+    off = synth.clip_offsets(counts)
+    seg, ctx = synth.video_features(counts, feat_dim, seed=123)
+    tokens = synth.query_tokens(nq, seed=123)
+    own, times = synth.annotations(nq, counts, seed=123)
+    sd = synth.model_weights(feat_dim, seed=123)
+    m = ref_model(sd, feat_dim)
+    ds, videos, annots = make_dataset(seg, ctx, off, tokens, own, times)
+    nmax = int(counts.max())
+
+    def iters():
+        vi = DataLoader(ds, shuffle=False, collate_fn=ref_data.validate_collate,
+                        batch_sampler=ref_data.VideoBatchSampler(videos, ds.num_segments_info))
+        ls = ref_data.LanguageBatchSampler(annots, ds.num_segments_info)
+        ls.moments = {n: ref_utils.generate_moments(n) for n in range(nmax + 1)}   # Q5: stock table stops at 6
+        li = DataLoader(ds, shuffle=False, collate_fn=ref_data.validate_collate, batch_sampler=ls)
+        return vi, li
+
+    np.random.seed(123); random.seed(123); torch.manual_seed(123)
+    vi, li = iters()
+    corpus = ref_evaluate.evaluate(m, vi, li, annots, "cpu")
+    prior = {}
+    rs = np.random.RandomState(9)
+    for n in sorted(set(counts.tolist())):
+        mom = ref_utils.generate_moments(n)
+        prior[n] = [mom[i] for i in rs.permutation(len(mom))]
+    random.seed(123)
+    vi, li = iters()
+    single = ref_evaluate_single.evaluate(m, vi, li, annots, "cpu", model_types=["model", "chance", "prior"], prior=prior)
+
+    # the reference's own expressions for embeddings, distances and moment means (evaluate.py:35,44,53-58)
+    with torch.no_grad():
+        vemb = {v: m(ds.make_visual_features(v, 0, ds.num_segments_info[v] - 1)) for v in videos}
+        qemb = torch.cat([m(ds.lang_features[q], False, "cpu") for q in range(nq)])
+    moments = {n: ref_utils.generate_moments(n) for n in range(nmax + 1)}
+    top_idx, top_dist, gaps, dense = [], [], [], []
+    for q in range(nq):
+        distances = []
+        for v in videos:
+            n = vemb[v].size(0)
+            dist = F.pairwise_distance(vemb[v], qemb[q:q + 1].repeat(n, 1))
+            for s, e in moments[n]:
+                distances.append(dist.index_select(0, torch.arange(s, e + 1)).mean().item())
+        d = np.asarray(distances)
+        order = np.argsort(d)
+        top_idx.append(order[:100]); top_dist.append(d[order[:100]].astype(np.float32))
+        gaps.append(np.diff(d[order[:101]]).astype(np.float32))
+        if q < 4:
+            dense.append(d.astype(np.float32))
+    out = dict(counts=counts, own=own, times=np.asarray(times, np.int32),
+               visual_emb=torch.cat([vemb[v] for v in videos]).numpy(), query_emb=qemb.numpy(),
+               top_idx=np.asarray(top_idx, np.int64), top_dist=np.asarray(top_dist), top_gaps=np.asarray(gaps),
+               dense_scores=np.asarray(dense), corpus_metrics=json.dumps(corpus),
+               single_metrics=json.dumps(single),
+               prior=json.dumps({str(k): v for k, v in prior.items()}))
+    np.savez_compressed(OUT / f"g2_scoring_{tag}.npz", **out)
+    print("G2", tag, corpus, {k: v for k, v in single.items() if k == "model"})
+
+
+def g3_moments_iou():
+    out = {}
+    for n in list(range(7)) + [21]:
+        out[f"moments_{n}"] = np.asarray(ref_utils.generate_moments(n), np.int32).reshape(-1, 2)
+    val = ref_utils.read_json(REF / "didemo_download" / "data" / "val_data.json")[:300]
+    times = [a["times"] for a in val]
+    ious = []
+    for t in times:
+        ious.append([ref_utils.get_iou(t, s, e) for s, e in ref_utils.generate_moments(6)])
+    lens = np.asarray([len(t) for t in times], np.int32)
+    flat = np.concatenate([np.asarray(t, np.int32) for t in times])
+    out.update(times_flat=flat, times_len=lens,
+               iou_flat=np.concatenate([np.asarray(i, np.float64).T.reshape(-1) for i in ious]))
+    np.savez_compressed(OUT / "g3_moments_iou.npz", **out)
+    print("G3", len(times), "annotations")
+
+
+def g4_pooling():
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        d = Path(td) / "features_vgg19"
+        d.mkdir()
+        names = []
+        for T in (150, 138, 125, 112):
+            x = np.random.RandomState(1000 + T).rand(T, 4096).astype(np.float32)
+            x[x < 0.3] = 0.0        # post-ReLU sparsity
+            np.save(d / f"vgg19_ft_vid{T}.npy", x)
+            names.append(f"vid{T}")
+        for mode in ("avg", "max"):
+            ds = ref_data.CustomDataset(names, {}, td, "vgg19", word_indexer=None, pooling=mode)
+            for T, name in zip((150, 138, 125, 112), names):
+                vf = ds.video_features[name]
+                out[f"seg_{mode}_{T}"] = vf["segment_features"].astype(np.float32)
+                out[f"ctx_{mode}_{T}"] = np.asarray(vf["context_features"], np.float32)
+                out[f"nseg_{mode}_{T}"] = np.int32(vf["num_segments"])
+    np.savez_compressed(OUT / "g4_pooling.npz", **out)
+    print("G4", sorted(out)[:4], "...")
+
+
+def g5_tokens():
+    val = ref_utils.read_json(REF / "didemo_download" / "data" / "val_data.json")
+    descs = sorted({a["description"] for a in val}, key=lambda s: (-len(s.split()), s))
+    sample = descs[:40] + descs[40::27][:260]          # the longest ones (> 20 words) + a spread
+    captured = []
+
+    class Recorder:                                     # stands in for WordIndexer inside load_lang_features
+        def items2tensor(self, seqs, size):
+            captured.append(list(seqs[0]))
+            return None
+
+    ds = ref_data.CustomDataset.__new__(ref_data.CustomDataset)
+    ds.word_indexer, ds.bert_tokenizer, ds.max_query_len, ds.lang_features = Recorder(), None, 20, {}
+    ds.load_lang_features({i: dict(description=s) for i, s in enumerate(sample)})
+    # a real WordIndexer on a tiny GloVe-format file (model/data.py:33-118)
+    vocab = sorted({w for words in captured for w in words})[::3][:150]
+    rs = np.random.RandomState(3)
+    with tempfile.TemporaryDirectory() as td:
+        lines = [f"{w} " + " ".join(f"{x:.5f}" for x in rs.randn(100)) for w in ["<unk>"] + vocab]
+        (Path(td) / "glove.6B.100d.txt").write_text("\n".join(lines) + "\n", encoding="UTF-8")
+        wi = ref_data.WordIndexer(td)
+        tensors = [wi.items2tensor([w], 20)[0].tolist() for w in captured]
+        emb = wi.get_embeddings().numpy()
+        glove_text = "\n".join(lines) + "\n"
+    json.dump(dict(descriptions=sample, words=captured, glove_text=glove_text, tensors=tensors,
+                   emb_checksum=float(np.abs(emb).sum()), vocab_size=int(emb.shape[0])),
+              open(OUT / "g5_tokens.json", "w"))
+    print("G5", len(sample), "descriptions, vocab", emb.shape)
+
+
+if __name__ == "__main__":
+    g3_moments_iou()
+    g5_tokens()
+    g4_pooling()
+    g1_encoders()
+    g2_scoring("n6", 6)
+    g2_scoring("ragged", "didemo")
+    g2_scoring("n21", 21)
