@@ -1,0 +1,155 @@
+/*
+ * vfr.h -- C ABI of libvfr.so: the MI355X (gfx950) cross-modal scoring hot path of
+ * video-fragments-retrieval.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * The reference has no FFI layer: its operator surface is Python (nn.Module calls and two
+ * evaluate() functions) and all arithmetic runs in implicit torch / torchvision / numpy vendor
+ * kernels.  Each entry point below replaces one such implicit call site; the citation names the
+ * reference file:line (relative to the reference repo root) whose arithmetic it takes over.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; row-major, fp32 unless typed
+ *   - the caller owns all memory, workspaces included (vfr_*_workspace_bytes tells how much);
+ *     the library never allocates or frees device memory and keeps no pointer after return
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *     no entry point synchronises with the host
+ *   - return 0 on success, a negative VFR_E* code otherwise; vfr_last_error() gives the message
+ *     (thread-local).  No exception, exit or abort crosses the boundary.
+ *   - stateless and re-entrant; weights are passed per call (no hidden model handle), so
+ *     load_state_dict()/.to() on the Python side keep working
+ *   - numerics: every contraction is one k-ascending fp32 fma chain (what v_mfma_f32_32x32x2_f32
+ *     computes), so results are bit-identical to oracle/vfr_oracle.c on any input
+ */
+#ifndef VFR_H
+#define VFR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library itself is built with -fvisibility=hidden */
+#endif
+
+#define VFR_OK 0
+#define VFR_EINVAL (-1)       /* null pointer, negative size, misaligned buffer                 */
+#define VFR_EUNSUPPORTED (-2) /* shape outside what the kernels are built for (message says)    */
+#define VFR_EHIP (-3)         /* a HIP runtime call failed; hipGetErrorString in the message    */
+#define VFR_EWORKSPACE (-4)   /* workspace smaller than vfr_*_workspace_bytes                   */
+
+typedef void *vfr_stream_t; /* hipStream_t */
+
+int vfr_version(void);
+const char *vfr_last_error(void);
+
+/* ---- a3  clip pooling: CustomDataset.load_video_features, model/data.py:163-181 -------------
+ * frames [T,F] -> seg [ceil(T/seg_len), F], ctx [F].  mode 0 = avg (np.mean), 1 = max (np.max);
+ * pooled row / (||pooled row||_2 + 1e-5).  F must be a multiple of 4.                           */
+int vfr_segment_pool_norm_f32(const float *frames, int T, int F, int seg_len, int mode, float *seg, float *ctx,
+                              vfr_stream_t stream);
+/* many videos at once: frames [sum T, F], frame_offsets [Nv+1] (int32, device),
+ * seg_offsets [Nv+1] = prefix sums of ceil(T_v/seg_len), total_segments = its last entry (host
+ * copy); seg [total_segments, F], ctx [Nv, F]                                                   */
+int vfr_segment_pool_norm_batch_f32(const float *frames, const int32_t *frame_offsets, const int32_t *seg_offsets,
+                                    int Nv, int total_segments, int F, int seg_len, int mode, float *seg,
+                                    float *ctx, vfr_stream_t stream);
+
+/* ---- a4 + a7  clip encoder: make_visual_features model/data.py:204-213 + CALModel visual
+ * branch model/models.py:21-26,55-56.  Row t of video v is [seg_t | ctx_v | t/n | (t+1)/n] x
+ * W1[hid, 2F+2] -> ReLU -> W2[D, hid]; the 2F+2 concat is never materialised and the context
+ * half of W1 is applied once per video.  clip_offsets [Nv+1] int32; out [total_clips, D].       */
+size_t vfr_visual_mlp_workspace_bytes(int total_clips, int Nv, int hid);
+int vfr_visual_mlp_f32(const float *seg, const float *ctx, const int32_t *clip_offsets, int Nv, int total_clips,
+                       int F, const float *W1, const float *b1, const float *W2, const float *b2, int hid, int D,
+                       float *out, void *workspace, size_t workspace_bytes, vfr_stream_t stream);
+
+/* ---- generic Linear (+ReLU): nn.Linear at model/models.py:31,59 (BERT branch) and the VGG
+ * classifier[0], classifier[3] (get_rgb_features.py:126).  out[M,N] = A[M,K] W[N,K]^T + b      */
+int vfr_linear_f32(const float *A, int64_t M, int K, const float *W, const float *b, int N, int relu, float *out,
+                   vfr_stream_t stream);
+
+/* ---- a8  query encoder: CALModel GloVe branch model/models.py:61-66 (+ init_hidden :50-52):
+ * Embedding gather [-> unit-norm x learnable length when len_tab != NULL, :62-64] -> BiLSTM(H),
+ * h0 = c0 = 0, all T steps including pads -> h_n [fwd|bwd] -> Linear(2H, D).
+ * tokens [B,T] int64; emb [vocab,E]; W_ih [4H,E], W_hh [4H,H], b_* [4H] (gate order i,f,g,o)
+ * for the forward (_f) and reverse (_b) directions; Wfc [D,2H]; out [B,D].                      */
+size_t vfr_bilstm_workspace_bytes(int64_t B, int T, int E, int H);
+int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *emb, int vocab, const float *len_tab,
+                         const float *Wih_f, const float *Whh_f, const float *bih_f, const float *bhh_f,
+                         const float *Wih_b, const float *Whh_b, const float *bih_b, const float *bhh_b, int E,
+                         int H, const float *Wfc, const float *bfc, int D, float *out, void *workspace,
+                         size_t workspace_bytes, vfr_stream_t stream);
+
+/* ---- a10  scoring core: model/evaluate.py:49-58 (same code evaluate_single.py:48-53,
+ * main.py:148-157).  dist[c] = ||(V[c] - q) + eps||_2 (F.pairwise_distance), score of moment
+ * (s,e) = mean(dist[s..e]); moments of a video in utils.generate_moments order
+ * (model/utils.py:71-75), videos concatenated in clip_offsets order.
+ * moment_offsets [Nv+1] int64 = prefix sums of n_v(n_v+1)/2.                                    */
+/* dense: scores [Nq, moment_offsets[Nv]]                                                        */
+int vfr_score_moments_f32(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets,
+                          const int64_t *moment_offsets, int Nv, int max_clips, int64_t total_moments, int D,
+                          float eps, float *scores, vfr_stream_t stream);
+/* each query against ONE video own[q] (evaluate_single.py:48-53): scores [Nq, Mmax], tail +inf  */
+int vfr_score_own_f32(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets, const int32_t *own,
+                      int max_clips, int D, float eps, int Mmax, float *scores, vfr_stream_t stream);
+
+/* ---- a12  ranking: np.argsort over all moments of all videos + R@k / MR, evaluate.py:67-80.
+ * Fused scoring + selection: never materialises the [Nq, sum M] score matrix.  Order is
+ * (distance, global moment id) ascending (the stable argsort).
+ *   k > 0 : out_dist [Nq,k] / out_idx [Nq,k] (int64 global moment ids) = the k best, padded
+ *           with (+inf, -1) when fewer than k moments exist
+ *   num_rank > 0 (<= 4) : rank_dist / rank_idx / count_lt are [num_rank, Nq]; count_lt[r][q] (int64)
+ *           += number of moments that sort strictly before (rank_dist[r][q], rank_idx[r][q]) --
+ *           evaluate.py:77's MR when that pair is the best ground-truth-positive moment of IoU
+ *           threshold r.  Counts are ADDED (zero the array first, or chain shards).
+ * id_base is added to every emitted / compared moment id (shard offset for multi-GPU, 8e).
+ * Limits: max_clips <= 64, k <= 448, id_base + total moments < 2^32.                           */
+size_t vfr_score_topk_workspace_bytes(int64_t Nq, int Nv, int k);
+int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets,
+                       const int64_t *moment_offsets, int Nv, int total_clips, int max_clips, int D, float eps,
+                       int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
+                       const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, void *workspace,
+                       size_t workspace_bytes, vfr_stream_t stream);
+/* merge G per-shard top-k lists (after the RCCL all-gather): part_dist/part_idx
+ * [G, Nq, k] -> out [Nq, k], same (distance, id) order.                                        */
+int vfr_topk_merge_f32(const float *part_dist, const int64_t *part_idx, int G, int64_t Nq, int k, float *out_dist,
+                       int64_t *out_idx, vfr_stream_t stream);
+
+/* ---- a1  frame normalisation: DiDeMoDataset.__getitem__ tail, get_rgb_features.py:64-69
+ * THWC uint8 -> TCHW fp32, ((x/255) - mean[c]) / std[c] with the ImageNet constants (:34-35)    */
+int vfr_frames_normalize_f32(const uint8_t *frames_thwc, int T, int H, int W, float *out_tchw, vfr_stream_t stream);
+
+/* ---- a2  VGG-19 "E" up to fc7: torchvision vgg19.features/avgpool/classifier[0..4],
+ * get_rgb_features.py:122-126,145-147.  Layer primitives (NCHW fp32):                           */
+int vfr_conv3x3_relu_f32(const float *x, int B, int Cin, int H, int W, const float *w /*[Cout,Cin,3,3]*/,
+                         const float *b, int Cout, float *y, vfr_stream_t stream);
+int vfr_maxpool2_f32(const float *x, int B, int C, int H, int W, float *y, vfr_stream_t stream);
+int vfr_adaptive_avgpool7_f32(const float *x, int B, int C, int H, int W, float *y, vfr_stream_t stream);
+/* whole stack: frames [T,H,W,3] u8 -> out [T, fc_dim].  cfg_host: ncfg ints, >0 = conv width,
+ * 0 = maxpool (VGG-19: 64,64,0,128,128,0,256x4,0,512x4,0,512x4,0).  conv_w/conv_b: HOST arrays
+ * of DEVICE pointers, one per conv.  fc6 [fc_dim, C_last*49], fc7 [fc_dim, fc_dim].             */
+size_t vfr_vgg_fc7_workspace_bytes(int T, int H, int W, const int *cfg_host, int ncfg, int fc_dim);
+int vfr_vgg_fc7_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *cfg_host, int ncfg,
+                    const float *const *conv_w_host, const float *const *conv_b_host, const float *fc6_w,
+                    const float *fc6_b, const float *fc7_w, const float *fc7_b, int fc_dim, float *out,
+                    void *workspace, size_t workspace_bytes, vfr_stream_t stream);
+
+/* ---- parity probe: elementwise canonical math (0 exp, 1 sigmoid, 2 tanh, 3 x/y, 4 sqrt,
+ * 5 fma(x,y,x)) so tests can pin the device's transcendental forms against the oracle's.        */
+int vfr_math_f32(int op, const float *x, const float *y, float *out, int64_t n, vfr_stream_t stream);
+
+/* ---- tuning / introspection (tests and bench only) -------------------------------------------
+ * vfr_set_option("gemm", 0|1): 0 = LDS-tiled VALU chain kernels, 1 = MFMA kernels (default).
+ * Both produce identical bits; the switch exists so tests can prove that on the device.         */
+int vfr_set_option(const char *name, int value);
+int vfr_get_option(const char *name);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFR_H */

@@ -21,7 +21,7 @@
  *       (this is exactly what v_mfma_f32_32x32x2_f32 computes; no split-K, no pairwise tree);
  *   R2  biases are added after the chain, unless a chain is documented to start from a C-in;
  *   R3  row reductions that must be parallel on the GPU (sum of squares over 4096 features) use
- *       the fixed "64 strided partials + xor butterfly 32..1" tree (tree64 below);
+ *       the fixed "64 lanes x strided float4 chunks + xor butterfly 32..1" tree (tree64 below);
  *   R4  no FMA contraction by the compiler (-ffp-contract=off); every fused op is an explicit fmaf;
  *   R5  exp/sigmoid/tanh are the polynomial forms below (IEEE ops only), sqrt and / are IEEE.
  *
@@ -90,13 +90,18 @@ VFO_EXPORT void vfo_math_f32(int op, const float *x, const float *y, float *out,
     }
 }
 
-/* R3: fixed reduction tree for sum of squares over a long row */
+/* R3: fixed reduction tree for sum of squares over a long row: lane l of 64 owns the float4 chunks
+ * l, l+64, l+128, ... (elements 4*chunk .. 4*chunk+3 in order), then an xor butterfly 32..1. */
 static float tree64_sumsq(const float *x, int n)
 {
     float p[64];
     for (int l = 0; l < 64; ++l) {
         float acc = 0.0f;
-        for (int i = l; i < n; i += 64) acc = fmaf(x[i], x[i], acc);
+        for (long chunk = l; chunk * 4 < n; chunk += 64)
+            for (int c = 0; c < 4; ++c) {
+                long j = chunk * 4 + c;
+                if (j < n) acc = fmaf(x[j], x[j], acc);
+            }
         p[l] = acc;
     }
     for (int off = 32; off >= 1; off >>= 1) {

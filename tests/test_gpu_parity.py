@@ -1,0 +1,315 @@
+"""Parity tests proper: every HIP kernel, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Bar: bit-exact (the kernels implement the oracle's canonical fp32 evaluation order), and
+within 1e-4 / identical top-k against the reference's own golden vectors."""
+import json
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import MemoryDataset, lstm_of, make_model, problem
+from vfr_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def vfr():
+    from vfr_amd import _vfr
+    _vfr.lib()
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    return _vfr
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.to(dtype) if dtype else t).to(DEV)
+
+
+def same(a, b):
+    """bit-for-bit as values (-0 == +0), NaN-free"""
+    a = a.cpu().numpy() if isinstance(a, torch.Tensor) else a
+    return a.shape == b.shape and np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_canonical_math_bit_exact(vfr, oracle):
+    rs = np.random.RandomState(0)
+    x = np.concatenate([rs.randn(200000) * 4, rs.uniform(-100, 100, 50000), [0.0, -0.0, 1e-30, 88.0, -88.0, 20.0]]).astype(np.float32)
+    y = np.concatenate([rs.uniform(0.5, 30, 200000), rs.randint(1, 22, 50006)]).astype(np.float32)
+    for op in (0, 1, 2, 5):
+        assert same(vfr.math_f32(op, dev(x), dev(y)), oracle.math_f32(op, x, y)), f"op {op}"
+    xp = np.abs(x)
+    assert same(vfr.math_f32(3, dev(xp), dev(y)), oracle.math_f32(3, xp, y))       # IEEE division
+    assert same(vfr.math_f32(4, dev(xp)), oracle.math_f32(4, xp))                  # IEEE sqrt
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 1, 1), (7, 100, 13), (130, 768, 100), (257, 1003, 70), (64, 4096, 500)])
+@pytest.mark.parametrize("gemm", [0, 1])
+def test_linear_bit_exact(vfr, oracle, M, K, N, gemm):
+    rs = np.random.RandomState(M + K + N)
+    A, W, b = rs.randn(M, K).astype(np.float32), rs.randn(N, K).astype(np.float32), rs.randn(N).astype(np.float32)
+    vfr.set_option("gemm", gemm)
+    try:
+        for relu in (False, True):
+            assert same(vfr.linear(dev(A), dev(W), dev(b), relu), oracle.linear(A, W, b, relu))
+        assert same(vfr.linear(dev(A), dev(W)), oracle.linear(A, W))
+    finally:
+        vfr.set_option("gemm", 1)
+
+
+@pytest.mark.parametrize("mode", ["avg", "max"])
+def test_segment_pool_norm(vfr, oracle, golden, mode):
+    g = golden("g4_pooling.npz")
+    frames, counts = [], []
+    for T in (150, 138, 125, 112, 1, 26):
+        x = np.random.RandomState(1000 + T).rand(T, 4096).astype(np.float32)
+        x[x < 0.3] = 0.0
+        seg, ctx = vfr.segment_pool_norm(dev(x), 25, mode)
+        oseg, octx = oracle.segment_pool_norm(x, 25, mode)
+        assert same(seg, oseg) and same(ctx, octx)
+        if T >= 112:
+            np.testing.assert_allclose(seg.cpu().numpy(), g[f"seg_{mode}_{T}"], rtol=0, atol=3e-7)
+            np.testing.assert_allclose(ctx.cpu().numpy(), g[f"ctx_{mode}_{T}"], rtol=0, atol=3e-7)
+        frames.append(x); counts.append(T)
+    seg, ctx, nseg = vfr.segment_pool_norm_batch(dev(np.concatenate(frames)), counts, 25, mode)
+    off = np.concatenate([[0], np.cumsum(nseg.numpy())])
+    for i, x in enumerate(frames):
+        oseg, octx = oracle.segment_pool_norm(x, 25, mode)
+        assert same(seg[off[i]:off[i + 1]], oseg) and same(ctx[i], octx)
+
+
+@pytest.mark.parametrize("gemm", [0, 1])
+def test_visual_mlp_bit_exact_and_golden(vfr, oracle, golden, gemm):
+    g = golden("g1_encoders.npz")
+    counts = g["counts"]
+    seg, ctx = synth.video_features(counts, 4096, seed=11)
+    sd = synth.model_weights(4096, seed=11)
+    off = synth.clip_offsets(counts)
+    vfr.set_option("gemm", gemm)
+    try:
+        got = vfr.visual_mlp(dev(seg), dev(ctx), dev(off), dev(sd["visual_fc.0.weight"]), dev(sd["visual_fc.0.bias"]),
+                             dev(sd["visual_fc.2.weight"]), dev(sd["visual_fc.2.bias"]))
+    finally:
+        vfr.set_option("gemm", 1)
+    want = oracle.visual_mlp(seg, ctx, off, sd["visual_fc.0.weight"], sd["visual_fc.0.bias"], sd["visual_fc.2.weight"],
+                             sd["visual_fc.2.bias"])
+    assert same(got, want)
+    np.testing.assert_allclose(got.cpu().numpy(), g["visual_emb"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("normlang", [False, True])
+def test_bilstm_bit_exact_and_golden(vfr, oracle, golden, normlang):
+    g = golden("g1_encoders.npz")
+    sd = synth.model_weights(4096, seed=11, normalize_lang=normlang)
+    tokens = g["tokens"]
+    lt = sd.get("learnable_length.weight")
+    got = vfr.bilstm_final(dev(tokens), dev(sd["word_embedding.weight"]), {k: dev(v) for k, v in lstm_of(sd).items()},
+                           dev(sd["lang_fc.weight"]), dev(sd["lang_fc.bias"]), dev(lt) if lt is not None else None)
+    want = oracle.bilstm_final(tokens, sd["word_embedding.weight"], lstm_of(sd), sd["lang_fc.weight"], sd["lang_fc.bias"], lt)
+    assert same(got, want)
+    np.testing.assert_allclose(got.cpu().numpy(), g["query_emb" + ("_normlang" if normlang else "")], rtol=0, atol=1e-4)
+
+
+def test_bilstm_odd_shapes(vfr, oracle):
+    sd = synth.model_weights(16, vocab=50, hidden=24, seed=5)
+    tokens = synth.query_tokens(67, vocab=50, seed=5)[:, :11]
+    got = vfr.bilstm_final(dev(tokens), dev(sd["word_embedding.weight"]), {k: dev(v) for k, v in lstm_of(sd).items()},
+                           dev(sd["lang_fc.weight"]), dev(sd["lang_fc.bias"]))
+    want = oracle.bilstm_final(tokens, sd["word_embedding.weight"], lstm_of(sd), sd["lang_fc.weight"], sd["lang_fc.bias"])
+    assert same(got, want)
+
+
+# ---------------------------------------------------------------------------------------------
+def _bank(vfr, V, off, id_base=0):
+    return vfr.VideoBank(dev(V), dev(off.astype(np.int32)), id_base)
+
+
+@pytest.mark.parametrize("tag,clips", [("n6", 6), ("ragged", "didemo"), ("n21", 21)])
+def test_scoring_on_reference_embeddings(vfr, oracle, golden, tag, clips):
+    """a10-a12 on the reference's own embeddings: dense scores, own-video scores, fused top-k and rank counts."""
+    g = golden(f"g2_scoring_{tag}.npz")
+    Q, V, counts = g["query_emb"], g["visual_emb"], g["counts"]
+    off = synth.clip_offsets(counts)
+    bank = _bank(vfr, V, off)
+    dense = vfr.score_moments(dev(Q), bank)
+    odense = oracle.score_moments(Q, V, off)
+    assert same(dense, odense)
+    np.testing.assert_allclose(dense.cpu().numpy()[:g["dense_scores"].shape[0]], g["dense_scores"], rtol=0, atol=1e-4)
+    own = g["own"].astype(np.int32)
+    nmax = int(counts.max())
+    assert same(vfr.score_own(dev(Q), bank, dev(own)), oracle.score_own(Q, V, off, own, nmax * (nmax + 1) // 2))
+    for k in (1, 10, 100, 200):
+        od, oi, _ = vfr.score_topk(dev(Q), bank, k)
+        wd, wi = oracle.score_topk(Q, V, off, k)
+        assert same(oi, wi), f"top-{k} moment indices differ"
+        assert same(od, wd)
+    # vs the reference's own argsort: top-1 and top-10 identical for every query
+    od, oi, _ = vfr.score_topk(dev(Q), bank, 100)
+    assert np.array_equal(oi.cpu().numpy()[:, :10], g["top_idx"][:, :10])
+    np.testing.assert_allclose(od.cpu().numpy(), g["top_dist"], rtol=0, atol=1e-4)
+    # rank counting for 3 arbitrary keys per query
+    rs = np.random.RandomState(1)
+    pick = rs.randint(0, odense.shape[1], size=(3, Q.shape[0]))
+    rd = np.take_along_axis(odense, pick.T, axis=1).T.copy()
+    _, _, cnt = vfr.score_topk(dev(Q), bank, 0, dev(rd), dev(pick.astype(np.int64)))
+    for r in range(3):
+        assert cnt[r].cpu().numpy().tolist() == oracle.rank_of(Q, V, off, rd[r], pick[r]).tolist()
+
+
+@pytest.mark.parametrize("nq,nv,clips,k,D", [(1, 1, 6, 100, 100), (65, 3, 5, 7, 100), (130, 40, 21, 128, 100),
+                                             (33, 17, "didemo", 100, 64), (5, 9, 64, 448, 100), (200, 600, 6, 100, 100)])
+def test_fused_topk_edge_shapes(vfr, oracle, nq, nv, clips, k, D):
+    rs = np.random.RandomState(nq * 1000 + nv)
+    counts = synth.clip_counts(nv, clips, seed=nq)
+    off = synth.clip_offsets(counts)
+    V = rs.randn(int(off[-1]), D).astype(np.float32)
+    Q = rs.randn(nq, D).astype(np.float32)
+    od, oi, _ = vfr.score_topk(dev(Q), _bank(vfr, V, off), k)
+    wd, wi = oracle.score_topk(Q, V, off, k)
+    assert same(oi, wi) and same(od, wd)
+
+
+def test_fused_topk_exact_ties_break_by_moment_id(vfr, oracle):
+    """Duplicate videos -> many exactly equal scores; order must be (score, id)."""
+    rs = np.random.RandomState(3)
+    one = rs.randn(6, 100).astype(np.float32)
+    V = np.tile(one, (50, 1))
+    off = synth.clip_offsets(np.full(50, 6))
+    Q = rs.randn(9, 100).astype(np.float32)
+    od, oi, _ = vfr.score_topk(dev(Q), _bank(vfr, V, off), 100)
+    wd, wi = oracle.score_topk(Q, V, off, 100)
+    assert same(oi, wi) and same(od, wd)
+    assert (np.diff(oi.cpu().numpy()[:, :50], axis=1) == 21).all()      # 50 copies of the best moment, ids 21 apart
+
+
+def test_topk_merge_and_shard_equivalence(vfr, oracle):
+    """Per-shard top-k with id_base, merged, equals the unsharded top-k; counts add up (8e semantics)."""
+    rs = np.random.RandomState(9)
+    counts = synth.clip_counts(90, "didemo", seed=9)
+    off = synth.clip_offsets(counts)
+    V = rs.randn(int(off[-1]), 100).astype(np.float32)
+    Q = rs.randn(70, 100).astype(np.float32)
+    mom = np.concatenate([[0], np.cumsum(counts * (counts + 1) // 2)])
+    wd, wi = oracle.score_topk(Q, V, off, 100)
+    full = oracle.score_moments(Q, V, off)
+    pick = rs.randint(0, full.shape[1], size=70)
+    rd = full[np.arange(70), pick].copy()
+    parts_d, parts_i, cnt = [], [], None
+    for lo, hi in ((0, 31), (31, 64), (64, 90)):
+        sub = (off[lo:hi + 1] - off[lo]).astype(np.int32)
+        bank = _bank(vfr, V[off[lo]:off[hi]], sub, id_base=int(mom[lo]))
+        d, i, cnt = vfr.score_topk(dev(Q), bank, 100, dev(rd), dev(pick.astype(np.int64)), count_lt=cnt)
+        parts_d.append(d); parts_i.append(i)
+    md, mi = vfr.topk_merge(torch.stack(parts_d), torch.stack(parts_i))
+    assert same(mi, wi) and same(md, wd)
+    assert cnt[0].cpu().numpy().tolist() == oracle.rank_of(Q, V, off, rd, pick).tolist()
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,clips", [("n6", 6), ("ragged", "didemo"), ("n21", 21)])
+def test_evaluators_end_to_end_on_gpu(vfr, oracle, golden, tag, clips):
+    """Drop-in surface on the device: same iterators, same dicts as the reference; embeddings == oracle bits."""
+    from vfr_amd import evaluate as vevaluate
+    from vfr_amd import evaluate_single as vsingle
+    g = golden(f"g2_scoring_{tag}.npz")
+    p = problem(100, 50, clips)
+    ds = MemoryDataset(p["seg"], p["ctx"], p["counts"], p["tokens"], p["own"], p["times"])
+    model = make_model(p["sd"]).to(DEV)
+    vi, li = ds.iterators()
+    got, (td, ti) = vevaluate.evaluate(model, vi, li, ds.annotations, DEV, return_topk=100)
+    ref = json.loads(str(g["corpus_metrics"]))
+    for key in ref:
+        assert got[key] == pytest.approx(ref[key], abs=1e-9), key
+    sd = p["sd"]
+    vis = oracle.visual_mlp(p["seg"], p["ctx"], p["off"], sd["visual_fc.0.weight"], sd["visual_fc.0.bias"],
+                            sd["visual_fc.2.weight"], sd["visual_fc.2.bias"])
+    qemb = oracle.bilstm_final(p["tokens"], sd["word_embedding.weight"], lstm_of(sd), sd["lang_fc.weight"], sd["lang_fc.bias"])
+    wd, wi = oracle.score_topk(qemb, vis, p["off"], 100)
+    assert same(ti, wi) and same(td, wd)                           # bit-exact moment indices, end to end
+    assert np.array_equal(ti.cpu().numpy()[:, :10], g["top_idx"][:, :10])
+    prior = {int(k): [tuple(m) for m in v] for k, v in json.loads(str(g["prior"])).items()}
+    random.seed(123)
+    vi, li = ds.iterators()
+    got = vsingle.evaluate(model, vi, li, ds.annotations, DEV, model_types=["model", "chance", "prior"], prior=prior)
+    ref = json.loads(str(g["single_metrics"]))
+    for key in ref:
+        assert got[key] == pytest.approx(ref[key], abs=1e-9), key
+
+
+def test_cal_model_forward_dispatch_on_gpu(vfr, golden):
+    g = golden("g1_encoders.npz")
+    sd = synth.model_weights(4096, seed=11)
+    model = make_model(sd).to(DEV)
+    seg, ctx = synth.video_features(g["counts"], 4096, seed=11)
+    ds = MemoryDataset(seg, ctx, g["counts"], g["tokens"], np.zeros(16, int), [[[0, 0]] * 4] * 16)
+    x = torch.cat([ds.make_visual_features(v, 0, ds.num_segments_info[v] - 1) for v in ds.videos]).to(DEV)
+    with torch.no_grad():
+        vis = model(x)                                             # generic [rows, 2F+2] path through vfr_linear_f32
+        q = model(dev(g["tokens"]), False, DEV)
+    np.testing.assert_allclose(vis.cpu().numpy(), g["visual_emb"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(q.cpu().numpy(), g["query_emb"], rtol=0, atol=1e-4)
+    rs = np.random.RandomState(5)
+    from vfr_amd import models as vmodels
+    mb = vmodels.CALModel(8194, pretrained_emb=None).to(DEV).eval()
+    W = rs.uniform(-0.08, 0.08, (100, 768)).astype(np.float32); b = rs.uniform(-0.08, 0.08, 100).astype(np.float32)
+    mb.lang_fc.load_state_dict({"weight": torch.from_numpy(W), "bias": torch.from_numpy(b)})
+    with torch.no_grad():
+        out = mb(dev(rs.randn(6, 768).astype(np.float32)), False, DEV, True)
+    np.testing.assert_allclose(out.cpu().numpy(), g["bert_out"], rtol=0, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+SMALL_VGG = [8, 8, "M", 16, 16, "M", 24, 24, 24, 24, "M", 32, 32, 32, 32, "M", 32, 32, 32, 32, "M"]
+
+
+@pytest.mark.parametrize("hw", [(32, 32), (64, 48)])
+def test_vgg_stack_bit_exact_reduced_width(vfr, oracle, hw):
+    H, W = hw
+    frames = synth.frames_u8(5, H, W, seed=2)
+    cw, cb, fc6, fc7 = synth.vgg_weights(SMALL_VGG, hw, 64, seed=2)
+    assert same(vfr.frames_normalize(dev(frames)), oracle.frames_normalize(frames))
+    x = oracle.frames_normalize(frames)
+    assert same(vfr.conv3x3_relu(dev(x), dev(cw[0]), dev(cb[0])), oracle.conv3x3_relu(x, cw[0], cb[0]))
+    y = oracle.conv3x3_relu(x, cw[0], cb[0])
+    assert same(vfr.maxpool2(dev(y)), oracle.maxpool2(y))
+    assert same(vfr.adaptive_avgpool7(dev(y)), oracle.adaptive_avgpool7(y))
+    got = vfr.vgg_fc7(dev(frames), SMALL_VGG, [dev(w) for w in cw], [dev(b) for b in cb],
+                      (dev(fc6[0]), dev(fc6[1])), (dev(fc7[0]), dev(fc7[1])))
+    want = oracle.vgg_fc7(frames, cw, cb, fc6, fc7, SMALL_VGG)
+    assert same(got, want)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_full_size_properties(vfr):
+    """BASELINE config 1 shape (10k videos x 21 clips) where the oracle is too slow: size-independent
+    properties -- shard-and-merge == unsharded, top-k sorted with unique ids, rank count consistent with the
+    list, sampled rows == dense kernel."""
+    torch.manual_seed(0)
+    nv, n, nq, k = 10000, 21, 256, 100
+    V = torch.randn(nv * n, 100, device=DEV)
+    Q = torch.randn(nq, 100, device=DEV)
+    off = torch.arange(0, nv * n + 1, n, dtype=torch.int32, device=DEV)
+    bank = vfr.VideoBank(V, off)
+    d, i, _ = vfr.score_topk(Q, bank, k)
+    assert bool((d[:, 1:] >= d[:, :-1]).all())
+    assert all(len(set(r)) == k for r in i.cpu().numpy().tolist())
+    half = nv // 2
+    M = n * (n + 1) // 2
+    b0 = vfr.VideoBank(V[:half * n].contiguous(), off[:half + 1].contiguous(), 0)
+    b1 = vfr.VideoBank(V[half * n:].contiguous(), (off[half:] - off[half]).contiguous(), half * M)
+    d0, i0, _ = vfr.score_topk(Q, b0, k)
+    d1, i1, _ = vfr.score_topk(Q, b1, k)
+    md, mi = vfr.topk_merge(torch.stack([d0, d1]), torch.stack([i0, i1]))
+    assert torch.equal(mi, i) and torch.equal(md, d)
+    # the 37th best moment has exactly 36 moments before it
+    _, _, cnt = vfr.score_topk(Q, bank, 0, d[:, 36].contiguous(), i[:, 36].contiguous())
+    assert bool((cnt[0] == 36).all())
+    # spot-check against the dense kernel on the videos that own the winners
+    top_vid = (i[:8, 0] // M).cpu().numpy()
+    for q, v in enumerate(top_vid):
+        sub = vfr.VideoBank(V[v * n:(v + 1) * n].contiguous(), off[:2].contiguous(), int(v) * M)
+        dense = vfr.score_moments(Q[q:q + 1].contiguous(), sub)
+        assert float(dense.min()) == float(d[q, 0])

@@ -1,0 +1,115 @@
+"""Host-side logic on the CPU device: utils / data mirror vs golden fixtures, and both evaluators driven
+through the reference's iterator contract (BASELINE config 0: 100 videos x 50 queries, no GPU)."""
+import json
+import random
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import MemoryDataset, make_model, problem
+from vfr_amd import data as vdata
+from vfr_amd import evaluate as vevaluate
+from vfr_amd import evaluate_single as vsingle
+from vfr_amd import utils as vutils
+
+
+def test_moments_and_iou_match_reference(golden):
+    g = golden("g3_moments_iou.npz")
+    for n in list(range(7)) + [21]:
+        mom = vutils.generate_moments(n)
+        assert mom == [tuple(r) for r in g[f"moments_{n}"].tolist()]
+        assert all(vutils.moment_index(n, s, e) == i for i, (s, e) in enumerate(mom))
+    lens, flat, ious = g["times_len"], g["times_flat"], g["iou_flat"]
+    p = o = 0
+    for L in lens:
+        times = flat[p:p + L].tolist()
+        got = np.asarray([vutils.get_iou(times, s, e) for s, e in vutils.generate_moments(6)]).T.reshape(-1)
+        assert np.array_equal(got, ious[o:o + got.size])
+        p += L; o += got.size
+
+
+def test_tokeniser_and_word_indexer_match_reference():
+    g = json.load(open(Path(__file__).parent / "golden" / "g5_tokens.json"))
+    words = [vdata.tokenize(d) for d in g["descriptions"]]
+    assert words == g["words"]
+    assert max(len(w) for w in words) > 20                       # the truncation case is present
+    with tempfile.TemporaryDirectory() as td:
+        (Path(td) / "glove.6B.100d.txt").write_text(g["glove_text"], encoding="UTF-8")
+        wi = vdata.WordIndexer(td)
+        assert wi.get_items_count() == g["vocab_size"]
+        got = [wi.items2tensor([w], 20)[0].tolist() for w in words]
+        assert got == g["tensors"]
+        assert float(np.abs(wi.get_embeddings().numpy()).sum()) == pytest.approx(g["emb_checksum"], rel=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["avg", "max"])
+def test_custom_dataset_pooling_host_path(golden, mode):
+    g = golden("g4_pooling.npz")
+    with tempfile.TemporaryDirectory() as td:
+        d = Path(td) / "features_vgg19"
+        d.mkdir()
+        names = []
+        for T in (150, 138, 125, 112):
+            x = np.random.RandomState(1000 + T).rand(T, 4096).astype(np.float32)
+            x[x < 0.3] = 0.0
+            np.save(d / f"vgg19_ft_vid{T}.npy", x)
+            names.append(f"vid{T}")
+        ds = vdata.CustomDataset(names, {}, td, "vgg19", pooling=mode, pool_device="cpu")
+        for T, name in zip((150, 138, 125, 112), names):
+            vf = ds.video_features[name]
+            assert vf["num_segments"] == int(g[f"nseg_{mode}_{T}"])
+            np.testing.assert_allclose(vf["segment_features"], g[f"seg_{mode}_{T}"], rtol=0, atol=3e-7)
+            np.testing.assert_allclose(vf["context_features"], g[f"ctx_{mode}_{T}"], rtol=0, atol=3e-7)
+        feat = ds.make_visual_features("vid150", 0, 5)
+        assert feat.shape == (6, 8194) and feat.dtype == torch.float32
+        np.testing.assert_allclose(feat[:, -2:].numpy(), [[t / 6, (t + 1) / 6] for t in range(6)], rtol=1e-6)
+        bank = ds.feature_bank()
+        assert bank.seg.shape == (6 + 6 + 5 + 5, 4096) and bank.clip_off.tolist() == [0, 6, 12, 17, 22]
+
+
+@pytest.mark.parametrize("tag,clips", [("n6", 6), ("ragged", "didemo"), ("n21", 21)])
+def test_evaluators_on_cpu_device_match_reference_dicts(golden, tag, clips):
+    g = golden(f"g2_scoring_{tag}.npz")
+    p = problem(100, 50, clips)
+    ds = MemoryDataset(p["seg"], p["ctx"], p["counts"], p["tokens"], p["own"], p["times"])
+    model = make_model(p["sd"])
+    vi, li = ds.iterators()
+    got = vevaluate.evaluate(model, vi, li, ds.annotations, "cpu")
+    ref = json.loads(str(g["corpus_metrics"]))
+    assert set(got) == set(ref)
+    for key in ref:
+        assert got[key] == pytest.approx(ref[key], abs=1e-9), key
+    prior = {int(k): [tuple(m) for m in v] for k, v in json.loads(str(g["prior"])).items()}
+    random.seed(123)
+    vi, li = ds.iterators()
+    got = vsingle.evaluate(model, vi, li, ds.annotations, "cpu", model_types=["model", "chance", "prior"], prior=prior)
+    ref = json.loads(str(g["single_metrics"]))
+    assert set(got) == set(ref)
+    for key in ref:
+        assert got[key] == pytest.approx(ref[key], abs=1e-9), key
+
+
+def test_cal_model_state_dict_surface():
+    sd = problem(2, 2, 6)["sd"]
+    m = make_model(sd)
+    keys = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert keys["visual_fc.0.weight"] == (500, 8194) and keys["visual_fc.2.weight"] == (100, 500)
+    assert keys["lstm.weight_hh_l0_reverse"] == (4000, 1000) and keys["lang_fc.weight"] == (100, 2000)
+    h = m.init_hidden(3, "cpu")
+    assert len(h) == 2 and h[0].shape == (2, 3, 1000)
+    m.train()
+    x = torch.randn(4, 8194, requires_grad=True)
+    m(x).sum().backward()                                         # autograd flows in training mode (main.py:66)
+    assert x.grad is not None
+
+
+def test_no_positive_moment_raises_like_reference():
+    p = problem(4, 3, 6)
+    times = [[[0, 0], [1, 1], [2, 2], [3, 3]]] * 3                # no two annotators agree -> no positive
+    ds = MemoryDataset(p["seg"], p["ctx"], p["counts"], p["tokens"], p["own"], times)
+    vi, li = ds.iterators()
+    with pytest.raises(IndexError):
+        vevaluate.evaluate(make_model(p["sd"]), vi, li, ds.annotations, "cpu")

@@ -1,0 +1,333 @@
+"""ctypes binding of ``lib/libvfr.so`` (C ABI: ``include/vfr.h``) for torch tensors on a ROCm device.
+
+PyTorch is plumbing here: it owns device memory and the stream; every kernel is ours.  Wrappers take
+``torch`` CUDA(=HIP) tensors, pass ``data_ptr()`` / sizes / ``torch.cuda.current_stream().cuda_stream``
+and raise ``RuntimeError`` with ``vfr_last_error()`` on a non-zero return.  There is NO fallback: if the
+shared library is missing or a tensor is not on the GPU these functions raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import torch
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libvfr.so"
+_lib = None
+
+_vp, _i32, _i64, _f32, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/vfr.h declares (checked by tests)
+SIGNATURES = {
+    "vfr_version": (_i32, []),
+    "vfr_last_error": (ctypes.c_char_p, []),
+    "vfr_set_option": (_i32, [ctypes.c_char_p, _i32]),
+    "vfr_get_option": (_i32, [ctypes.c_char_p]),
+    "vfr_math_f32": (_i32, [_i32, _vp, _vp, _vp, _i64, _vp]),
+    "vfr_segment_pool_norm_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "vfr_segment_pool_norm_batch_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "vfr_visual_mlp_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "vfr_visual_mlp_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "vfr_linear_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "vfr_bilstm_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "vfr_bilstm_final_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp] + [_vp] * 8 + [_i32, _i32, _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "vfr_score_moments_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _vp, _vp]),
+    "vfr_score_own_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp]),
+    "vfr_score_topk_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "vfr_score_topk_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i64, _i32, _vp, _vp, _i32,
+                                  _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vfr_topk_merge_f32": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "vfr_frames_normalize_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "vfr_conv3x3_relu_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "vfr_maxpool2_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vfr_adaptive_avgpool7_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vfr_vgg_fc7_workspace_bytes": (_sz, [_i32, _i32, _i32, _vp, _i32, _i32]),
+    "vfr_vgg_fc7_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
+}
+
+
+def build(force: bool = False) -> Path:
+    """Compile the HIP sources for gfx950 (``make`` drives hipcc; cross-compiles without a GPU)."""
+    cmd = ["make", "-C", str(_PKG / "csrc"), "-j8"] + (["-B"] if force else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("libvfr.so build failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no fallback path for the HIP kernels)")
+        l = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().vfr_last_error().decode()}")
+
+
+def _dev(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the ROCm device (no CPU fallback in the HIP path)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def set_option(name: str, value: int) -> None:
+    _check(lib().vfr_set_option(name.encode(), int(value)), "vfr_set_option")
+
+
+def get_option(name: str) -> int:
+    return int(lib().vfr_get_option(name.encode()))
+
+
+# ------------------------------------------------------------------------------------------------
+def math_f32(op: int, x: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:
+    x = _dev(x, torch.float32, "x")
+    y = _dev(y, torch.float32, "y") if y is not None else None
+    out = torch.empty_like(x)
+    _check(lib().vfr_math_f32(op, x.data_ptr(), _ptr(y), out.data_ptr(), x.numel(), _stream()), "vfr_math_f32")
+    return out
+
+
+def segment_pool_norm(frames: torch.Tensor, seg_len: int = 25, mode: str = "avg"):
+    """[T,F] fc7 frames -> (seg [ceil(T/seg_len),F], ctx [F])  (model/data.py:163-181)."""
+    frames = _dev(frames, torch.float32, "frames")
+    T, F = frames.shape
+    nseg = (T + seg_len - 1) // seg_len
+    seg = torch.empty((nseg, F), dtype=torch.float32, device=frames.device)
+    ctx = torch.empty((F,), dtype=torch.float32, device=frames.device)
+    _check(lib().vfr_segment_pool_norm_f32(frames.data_ptr(), T, F, seg_len, 0 if mode == "avg" else 1,
+                                           seg.data_ptr(), ctx.data_ptr(), _stream()), "vfr_segment_pool_norm_f32")
+    return seg, ctx
+
+
+def segment_pool_norm_batch(frames: torch.Tensor, frame_counts, seg_len: int = 25, mode: str = "avg"):
+    """frames [sum T, F] for many videos, frame_counts = list of T_v -> (seg [sum n,F], ctx [Nv,F], clip_counts)."""
+    frames = _dev(frames, torch.float32, "frames")
+    F = frames.shape[1]
+    counts = torch.as_tensor(list(frame_counts), dtype=torch.int64)
+    nseg = (counts + seg_len - 1) // seg_len
+    foff = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)]).to(torch.int32).to(frames.device)
+    soff = torch.cat([torch.zeros(1, dtype=torch.int64), nseg.cumsum(0)]).to(torch.int32).to(frames.device)
+    total = int(nseg.sum())
+    Nv = len(counts)
+    seg = torch.empty((total, F), dtype=torch.float32, device=frames.device)
+    ctx = torch.empty((Nv, F), dtype=torch.float32, device=frames.device)
+    _check(lib().vfr_segment_pool_norm_batch_f32(frames.data_ptr(), foff.data_ptr(), soff.data_ptr(), Nv, total, F,
+                                                 seg_len, 0 if mode == "avg" else 1, seg.data_ptr(), ctx.data_ptr(),
+                                                 _stream()), "vfr_segment_pool_norm_batch_f32")
+    return seg, ctx, nseg.to(torch.int32)
+
+
+def visual_mlp(seg, ctx, clip_off, W1, b1, W2, b2) -> torch.Tensor:
+    seg, ctx = _dev(seg, torch.float32, "seg"), _dev(ctx, torch.float32, "ctx")
+    W1, b1, W2, b2 = (_dev(t, torch.float32, n) for t, n in ((W1, "W1"), (b1, "b1"), (W2, "W2"), (b2, "b2")))
+    clip_off = _dev(clip_off, torch.int32, "clip_off")
+    C, F = seg.shape
+    Nv, hid, D = ctx.shape[0], W1.shape[0], W2.shape[0]
+    if W1.shape[1] != 2 * F + 2 or clip_off.numel() != Nv + 1 or W2.shape[1] != hid:
+        raise RuntimeError("visual_mlp: inconsistent shapes")
+    out = torch.empty((C, D), dtype=torch.float32, device=seg.device)
+    ws_bytes = lib().vfr_visual_mlp_workspace_bytes(C, Nv, hid)
+    ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=seg.device)
+    _check(lib().vfr_visual_mlp_f32(seg.data_ptr(), ctx.data_ptr(), clip_off.data_ptr(), Nv, C, F, W1.data_ptr(),
+                                    b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), hid, D, out.data_ptr(), ws.data_ptr(),
+                                    ws_bytes, _stream()), "vfr_visual_mlp_f32")
+    return out
+
+
+def linear(A, W, b=None, relu: bool = False) -> torch.Tensor:
+    A, W = _dev(A, torch.float32, "A"), _dev(W, torch.float32, "W")
+    b = _dev(b, torch.float32, "b") if b is not None else None
+    out = torch.empty((A.shape[0], W.shape[0]), dtype=torch.float32, device=A.device)
+    _check(lib().vfr_linear_f32(A.data_ptr(), A.shape[0], A.shape[1], W.data_ptr(), _ptr(b), W.shape[0], int(relu),
+                                out.data_ptr(), _stream()), "vfr_linear_f32")
+    return out
+
+
+_LSTM_NAMES = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")
+
+
+def bilstm_final(tokens, emb, lstm: dict, Wfc, bfc, len_tab=None) -> torch.Tensor:
+    """tokens int64 [B,T] -> query embeddings [B,D]  (model/models.py:61-66)."""
+    tokens = _dev(tokens, torch.int64, "tokens")
+    emb = _dev(emb, torch.float32, "emb")
+    ws_ = [_dev(lstm[n], torch.float32, n) for n in _LSTM_NAMES] + \
+          [_dev(lstm[n + "_reverse"], torch.float32, n + "_reverse") for n in _LSTM_NAMES]
+    Wfc, bfc = _dev(Wfc, torch.float32, "Wfc"), _dev(bfc, torch.float32, "bfc")
+    lt = _dev(len_tab, torch.float32, "len_tab") if len_tab is not None else None
+    B, T = tokens.shape
+    E, H, D = emb.shape[1], ws_[1].shape[1], Wfc.shape[0]
+    out = torch.empty((B, D), dtype=torch.float32, device=tokens.device)
+    nbytes = lib().vfr_bilstm_workspace_bytes(B, T, E, H)
+    ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=tokens.device)
+    _check(lib().vfr_bilstm_final_f32(tokens.data_ptr(), B, T, emb.data_ptr(), emb.shape[0], _ptr(lt),
+                                      *[w.data_ptr() for w in ws_], E, H, Wfc.data_ptr(), bfc.data_ptr(), D,
+                                      out.data_ptr(), ws.data_ptr(), nbytes, _stream()), "vfr_bilstm_final_f32")
+    return out
+
+
+def moment_offsets(clip_off: torch.Tensor) -> torch.Tensor:
+    n = (clip_off[1:] - clip_off[:-1]).to(torch.int64)
+    return torch.cat([torch.zeros(1, dtype=torch.int64, device=clip_off.device), (n * (n + 1) // 2).cumsum(0)])
+
+
+class VideoBank:
+    """Clip embeddings of a (shard of a) corpus resident in HBM, with the CSR offsets the kernels take.
+
+    ``emb`` [sum n, D] fp32, ``clip_off`` [Nv+1] int32, ``mom_off`` [Nv+1] int64 (all on the device);
+    ``max_clips`` / ``total_moments`` are host ints computed once at construction (one D2H of two scalars).
+    """
+
+    def __init__(self, emb: torch.Tensor, clip_off: torch.Tensor, id_base: int = 0):
+        self.emb = _dev(emb, torch.float32, "emb")
+        self.clip_off = _dev(clip_off, torch.int32, "clip_off")
+        self.mom_off = moment_offsets(self.clip_off)
+        n = self.clip_off[1:] - self.clip_off[:-1]
+        self.num_videos = int(self.clip_off.numel() - 1)
+        self.max_clips = int(n.max()) if self.num_videos else 0
+        self.total_clips = int(self.emb.shape[0])
+        self.total_moments = int(self.mom_off[-1])
+        self.id_base = int(id_base)
+        self.dim = int(self.emb.shape[1])
+
+
+def score_moments(Q: torch.Tensor, bank: VideoBank, eps: float = 1e-6) -> torch.Tensor:
+    Q = _dev(Q, torch.float32, "Q")
+    out = torch.empty((Q.shape[0], bank.total_moments), dtype=torch.float32, device=Q.device)
+    _check(lib().vfr_score_moments_f32(Q.data_ptr(), Q.shape[0], bank.emb.data_ptr(), bank.clip_off.data_ptr(),
+                                       bank.mom_off.data_ptr(), bank.num_videos, bank.max_clips, bank.total_moments,
+                                       bank.dim, eps, out.data_ptr(), _stream()), "vfr_score_moments_f32")
+    return out
+
+
+def score_own(Q: torch.Tensor, bank: VideoBank, own: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    Q = _dev(Q, torch.float32, "Q")
+    own = _dev(own, torch.int32, "own")
+    Mmax = bank.max_clips * (bank.max_clips + 1) // 2
+    out = torch.empty((Q.shape[0], Mmax), dtype=torch.float32, device=Q.device)
+    _check(lib().vfr_score_own_f32(Q.data_ptr(), Q.shape[0], bank.emb.data_ptr(), bank.clip_off.data_ptr(),
+                                   own.data_ptr(), bank.max_clips, bank.dim, eps, Mmax, out.data_ptr(), _stream()),
+           "vfr_score_own_f32")
+    return out
+
+
+def score_topk(Q: torch.Tensor, bank: VideoBank, k: int, rank_dist=None, rank_idx=None, count_lt=None,
+               eps: float = 1e-6, workspace: torch.Tensor | None = None):
+    """Fused scoring + top-k (+ rank counting for up to 4 keys per query).
+
+    rank_dist / rank_idx: [R, Nq] (or [Nq]) -> count_lt [R, Nq] int64 is ADDED to (allocated zeroed when None).
+    Returns (dist [Nq,k] | None, idx [Nq,k] int64 | None, count_lt | None)."""
+    Q = _dev(Q, torch.float32, "Q")
+    Nq = Q.shape[0]
+    od = torch.empty((Nq, k), dtype=torch.float32, device=Q.device) if k > 0 else None
+    oi = torch.empty((Nq, k), dtype=torch.int64, device=Q.device) if k > 0 else None
+    R = 0
+    if rank_dist is not None:
+        rank_dist = _dev(rank_dist, torch.float32, "rank_dist").reshape(-1, Nq)
+        rank_idx = _dev(rank_idx, torch.int64, "rank_idx").reshape(-1, Nq)
+        R = rank_dist.shape[0]
+        if count_lt is None:
+            count_lt = torch.zeros((R, Nq), dtype=torch.int64, device=Q.device)
+        count_lt = _dev(count_lt, torch.int64, "count_lt")
+    nbytes = lib().vfr_score_topk_workspace_bytes(Nq, bank.num_videos, k)
+    if workspace is None or workspace.numel() < nbytes:
+        workspace = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=Q.device)
+    _check(lib().vfr_score_topk_f32(Q.data_ptr(), Nq, bank.emb.data_ptr(), bank.clip_off.data_ptr(),
+                                    bank.mom_off.data_ptr(), bank.num_videos, bank.total_clips, bank.max_clips,
+                                    bank.dim, eps, bank.id_base, k, _ptr(od), _ptr(oi), R, _ptr(rank_dist),
+                                    _ptr(rank_idx), _ptr(count_lt), workspace.data_ptr(), nbytes, _stream()),
+           "vfr_score_topk_f32")
+    return od, oi, count_lt
+
+
+def topk_workspace(Nq: int, num_videos: int, k: int, device) -> torch.Tensor:
+    return torch.empty((max(lib().vfr_score_topk_workspace_bytes(Nq, num_videos, k), 1),), dtype=torch.uint8,
+                       device=device)
+
+
+def topk_merge(part_dist: torch.Tensor, part_idx: torch.Tensor):
+    """[G,Nq,k] shard lists -> merged [Nq,k] in (distance, id) order."""
+    pd, pi = _dev(part_dist, torch.float32, "part_dist"), _dev(part_idx, torch.int64, "part_idx")
+    G, Nq, k = pd.shape
+    od = torch.empty((Nq, k), dtype=torch.float32, device=pd.device)
+    oi = torch.empty((Nq, k), dtype=torch.int64, device=pd.device)
+    _check(lib().vfr_topk_merge_f32(pd.data_ptr(), pi.data_ptr(), G, Nq, k, od.data_ptr(), oi.data_ptr(), _stream()),
+           "vfr_topk_merge_f32")
+    return od, oi
+
+
+def frames_normalize(frames_thwc: torch.Tensor) -> torch.Tensor:
+    fr = _dev(frames_thwc, torch.uint8, "frames")
+    T, H, W, _ = fr.shape
+    out = torch.empty((T, 3, H, W), dtype=torch.float32, device=fr.device)
+    _check(lib().vfr_frames_normalize_f32(fr.data_ptr(), T, H, W, out.data_ptr(), _stream()), "vfr_frames_normalize_f32")
+    return out
+
+
+def conv3x3_relu(x, w, b) -> torch.Tensor:
+    x, w, b = _dev(x, torch.float32, "x"), _dev(w, torch.float32, "w"), _dev(b, torch.float32, "b")
+    B, Cin, H, W = x.shape
+    y = torch.empty((B, w.shape[0], H, W), dtype=torch.float32, device=x.device)
+    _check(lib().vfr_conv3x3_relu_f32(x.data_ptr(), B, Cin, H, W, w.data_ptr(), b.data_ptr(), w.shape[0], y.data_ptr(),
+                                      _stream()), "vfr_conv3x3_relu_f32")
+    return y
+
+
+def maxpool2(x) -> torch.Tensor:
+    x = _dev(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    _check(lib().vfr_maxpool2_f32(x.data_ptr(), B, C, H, W, y.data_ptr(), _stream()), "vfr_maxpool2_f32")
+    return y
+
+
+def adaptive_avgpool7(x) -> torch.Tensor:
+    x = _dev(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, 7, 7), dtype=torch.float32, device=x.device)
+    _check(lib().vfr_adaptive_avgpool7_f32(x.data_ptr(), B, C, H, W, y.data_ptr(), _stream()), "vfr_adaptive_avgpool7_f32")
+    return y
+
+
+def vgg_fc7(frames_thwc, cfg, conv_w, conv_b, fc6, fc7) -> torch.Tensor:
+    """uint8 [T,H,W,3] -> fc7 features [T, fc_dim]  (get_rgb_features.py:64-69,122-126,145-147)."""
+    fr = _dev(frames_thwc, torch.uint8, "frames")
+    T, H, W, _ = fr.shape
+    cfg_i = (ctypes.c_int * len(cfg))(*[0 if c == "M" else int(c) for c in cfg])
+    cw = [_dev(w, torch.float32, "conv_w") for w in conv_w]
+    cb = [_dev(b, torch.float32, "conv_b") for b in conv_b]
+    wp = (ctypes.c_void_p * len(cw))(*[w.data_ptr() for w in cw])
+    bp = (ctypes.c_void_p * len(cb))(*[b.data_ptr() for b in cb])
+    f6w, f6b = _dev(fc6[0], torch.float32, "fc6_w"), _dev(fc6[1], torch.float32, "fc6_b")
+    f7w, f7b = _dev(fc7[0], torch.float32, "fc7_w"), _dev(fc7[1], torch.float32, "fc7_b")
+    fc_dim = f6w.shape[0]
+    out = torch.empty((T, fc_dim), dtype=torch.float32, device=fr.device)
+    nbytes = lib().vfr_vgg_fc7_workspace_bytes(T, H, W, ctypes.cast(cfg_i, ctypes.c_void_p), len(cfg), fc_dim)
+    ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=fr.device)
+    _check(lib().vfr_vgg_fc7_f32(fr.data_ptr(), T, H, W, ctypes.cast(cfg_i, ctypes.c_void_p), len(cfg),
+                                 ctypes.cast(wp, ctypes.c_void_p), ctypes.cast(bp, ctypes.c_void_p), f6w.data_ptr(),
+                                 f6b.data_ptr(), f7w.data_ptr(), f7b.data_ptr(), fc_dim, out.data_ptr(), ws.data_ptr(),
+                                 nbytes, _stream()), "vfr_vgg_fc7_f32")
+    return out

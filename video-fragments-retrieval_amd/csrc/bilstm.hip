@@ -1,0 +1,137 @@
+// a8: query encoder = CALModel GloVe branch (model/models.py:61-66): Embedding gather
+// [-> unit-norm x learnable length, :62-64] -> 1-layer BiLSTM(H), zero initial state (:50-52), every
+// one of the T steps processed (pads included, Q6) -> [h_fwd | h_bwd] -> Linear(2H, D).
+//
+//   X    [B*T, E]   = emb[tokens]                                   gather (+ optional normalise)
+//   Gin_d[B*T, 4H]  = X x Wih_d^T + (bih_d + bhh_d)                 hoisted input projection, d = fwd/bwd
+//   per step t:  gates = Gin_d[:, t] (C-in) + h_d x Whh_d^T         chain GEMM starting FROM the C-in
+//                i,f,o = sigmoid, g = tanh; c' = fma(f, c, i*g); h' = o * tanh(c')
+//   out  [B, D]     = [h_fwd | h_bwd] x Wfc^T + bfc
+//
+// 352.4 MFLOP per query; the recurrent GEMM [B,H]x[H,4H] is the MFMA-bound part.
+#include "vfr_common.h"
+#include "vfr_math.cuh"
+
+namespace vfr {
+
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t *__restrict__ tokens, int64_t rows, int vocab,
+                                                    const float *__restrict__ emb, const float *__restrict__ len_tab,
+                                                    int E, float *__restrict__ X)
+{
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    int64_t tok = tokens[r];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);   // never read outside the table
+    const float *e = emb + tok * E;
+    float *x = X + r * E;
+    if (!len_tab) {
+        for (int k = 0; k < E; ++k) x[k] = e[k];
+        return;
+    }
+    float acc = 0.0f;
+    for (int k = 0; k < E; ++k) acc = __builtin_fmaf(e[k], e[k], acc);
+    const float nrm = __builtin_sqrtf(acc) + 1e-5f, len = len_tab[tok];
+    for (int k = 0; k < E; ++k) x[k] = (e[k] / nrm) * len;
+}
+
+// gates [2][B,4H] -> c [2][B,H] (in place), h written into hcat [B, 2H] at column d*H
+__global__ __launch_bounds__(256) void lstm_pointwise_kernel(const float *__restrict__ gates, float *__restrict__ c,
+                                                             float *__restrict__ hcat, int64_t B, int H)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t per = B * H;
+    if (i >= 2 * per) return;
+    int d = (int)(i / per);
+    int64_t r = i - d * per, b = r / H;
+    int j = (int)(r - b * H);
+    const float *g4 = gates + ((int64_t)d * B + b) * 4 * H;
+    float ig = c_sigmoidf(g4[j]);
+    float fg = c_sigmoidf(g4[H + j]);
+    float gg = c_tanhf(g4[2 * H + j]);
+    float og = c_sigmoidf(g4[3 * H + j]);
+    float cn = __builtin_fmaf(fg, c[i], ig * gg);
+    c[i] = cn;
+    hcat[b * 2 * H + (int64_t)d * H + j] = og * c_tanhf(cn);
+}
+
+struct LstmWs {
+    float *X, *gin[2], *gates, *c, *hcat;
+    size_t total;
+};
+static LstmWs carve(void *base, int64_t B, int T, int E, int H)
+{
+    LstmWs w{};
+    size_t off = 0;
+    auto take = [&](size_t n) { float *p = reinterpret_cast<float *>(static_cast<char *>(base) + off);
+                                off += align_up(n * sizeof(float), 256); return p; };
+    w.X = take((size_t)B * T * E);
+    w.gin[0] = take((size_t)B * T * 4 * H);
+    w.gin[1] = take((size_t)B * T * 4 * H);
+    w.gates = take((size_t)2 * B * 4 * H);
+    w.c = take((size_t)2 * B * H);
+    w.hcat = take((size_t)B * 2 * H);
+    w.total = off;
+    return w;
+}
+
+}  // namespace vfr
+
+extern "C" {
+
+size_t vfr_bilstm_workspace_bytes(int64_t B, int T, int E, int H)
+{
+    if (B < 0 || T < 0 || E < 0 || H < 0) return 0;
+    return vfr::carve(nullptr, B, T, E, H).total;
+}
+
+int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *emb, int vocab, const float *len_tab,
+                         const float *Wih_f, const float *Whh_f, const float *bih_f, const float *bhh_f,
+                         const float *Wih_b, const float *Whh_b, const float *bih_b, const float *bhh_b, int E,
+                         int H, const float *Wfc, const float *bfc, int D, float *out, void *workspace,
+                         size_t workspace_bytes, vfr_stream_t stream)
+{
+    VFR_REQUIRE(tokens && emb && Wih_f && Whh_f && bih_f && bhh_f && Wih_b && Whh_b && bih_b && bhh_b && Wfc && bfc &&
+                    out && B >= 0 && T > 0 && E > 0 && H > 0 && D > 0 && vocab > 0,
+                VFR_EINVAL, "vfr_bilstm_final_f32: bad argument");
+    if (B == 0) return VFR_OK;
+    VFR_REQUIRE(workspace && workspace_bytes >= vfr_bilstm_workspace_bytes(B, T, E, H), VFR_EWORKSPACE,
+                "vfr_bilstm_final_f32: workspace %zu < %zu bytes", workspace_bytes,
+                vfr_bilstm_workspace_bytes(B, T, E, H));
+    hipStream_t st = vfr::as_stream(stream);
+    vfr::LstmWs w = vfr::carve(workspace, B, T, E, H);
+    const float *Wih[2] = {Wih_f, Wih_b}, *Whh[2] = {Whh_f, Whh_b};
+    const float *bih[2] = {bih_f, bih_b}, *bhh[2] = {bhh_f, bhh_b};
+    const int G = 4 * H;
+
+    hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(B * T, 256)), dim3(256), 0, st, tokens, B * T, vocab,
+                       emb, len_tab, E, w.X);
+    VFR_CHECK_LAUNCH("embed_kernel");
+    for (int d = 0; d < 2; ++d) {
+        vfr::GemmArgs g{};
+        g.A = w.X; g.lda = E; g.W = Wih[d]; g.ldw = E; g.out = w.gin[d]; g.ldo = G; g.M = B * T; g.N = G; g.K = E;
+        g.bias = bih[d]; g.bias2 = bhh[d]; g.epi = vfr::EPI_BIAS2;
+        if (int rc = vfr::gemm_nt(g, st)) return rc;
+    }
+    if (hipMemsetAsync(w.c, 0, (size_t)2 * B * H * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(w.hcat, 0, (size_t)B * 2 * H * sizeof(float), st) != hipSuccess)
+        return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: hipMemsetAsync failed");
+    for (int step = 0; step < T; ++step) {
+        for (int d = 0; d < 2; ++d) {
+            const int t = d ? T - 1 - step : step;
+            vfr::GemmArgs g{};
+            g.A = w.hcat + (size_t)d * H; g.lda = 2 * H; g.W = Whh[d]; g.ldw = H;
+            g.Cin = w.gin[d] + (size_t)t * G; g.ldc = (int64_t)T * G;
+            g.out = w.gates + (size_t)d * B * G; g.ldo = G; g.M = B; g.N = G; g.K = H;
+            if (int rc = vfr::gemm_nt(g, st)) return rc;
+        }
+        hipLaunchKernelGGL(vfr::lstm_pointwise_kernel, dim3((unsigned)vfr::cdiv(2 * B * H, 256)), dim3(256), 0, st,
+                           w.gates, w.c, w.hcat, B, H);
+        VFR_CHECK_LAUNCH("lstm_pointwise_kernel");
+    }
+    vfr::GemmArgs g{};
+    g.A = w.hcat; g.lda = 2 * H; g.W = Wfc; g.ldw = 2 * H; g.out = out; g.ldo = D; g.M = B; g.N = D; g.K = 2 * H;
+    g.bias = bfc; g.epi = vfr::EPI_BIAS;
+    return vfr::gemm_nt(g, st);
+}
+
+}  // extern "C"

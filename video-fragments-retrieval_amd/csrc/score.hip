@@ -1,0 +1,591 @@
+// a10 + a12: moment scoring and ranking (model/evaluate.py:49-80, evaluate_single.py:48-54).
+//
+//   dist[c]    = || (V[c] - q) + eps ||_2          F.pairwise_distance, eps on the difference (Q8)
+//   score(s,e) = (dist[s] + ... + dist[e]) / (e-s+1)   index_select().mean()
+//   ranking    = ascending (score, global moment id)    np.argsort, made deterministic
+//
+// Mapping onto gfx950 (exact fp32, VALU-bound: the direct-difference form is not a GEMM):
+//   * thread = query.  A wave owns 64 queries; each lane keeps its query embedding (D = 100 floats)
+//     in VGPRs for the whole kernel -- the per-query embedding tile is register-resident.
+//   * the clip embedding being scored is the same for all 64 lanes, so V streams through the scalar
+//     cache into SGPRs (s_load_dwordxN) and feeds the VALU as a scalar operand: every V byte is read
+//     once per wave, coalesced by construction, no LDS staging and no bank conflicts.
+//   * 4 clips are scored at a time (4 independent fma chains per lane) for ILP; the clip distances of
+//     the current video go to a per-wave LDS column (ds[c][lane], conflict-free), from which each lane
+//     walks the moment triangle sequentially (the canonical summation order).
+//   * selection: each lane filters against its own threshold (the k-th best key seen so far, shared
+//     between all waves working on the same query through a global atomicMin) and appends survivors
+//     to its candidate buffer; when a buffer fills, the wave sorts it cooperatively with a register
+//     bitonic network (64 lanes x KPL keys, cross-lane exchanges by wave shuffles) and keeps the k
+//     best.  A wave never synchronises with another wave.
+//   * keys are (fp32 bits of score << 32 | moment id): scores are >= 0 so unsigned order == the
+//     (score, id) lexicographic order, one 64-bit compare per test.
+#include "vfr_common.h"
+#include "vfr_math.cuh"
+
+namespace vfr {
+
+constexpr int NMAX_FUSED = 64;    // max clips per video on the fused path
+constexpr int NMAX_DENSE = 128;   // max clips per video on the dense / own paths
+constexpr unsigned long long KEY_MAX = ~0ull;
+constexpr int MAX_RANK = 4;       // rank keys per query counted in one pass (IoU thresholds)
+
+// ------------------------------------------------------------------------------------------------
+// distance of NC (<= 4) clips to this lane's query: D is a template constant when DT > 0 (query in
+// registers), runtime when DT == 0 (query re-read from global, L1-resident).
+// ------------------------------------------------------------------------------------------------
+template <int DT, int NC>
+__device__ __forceinline__ void clip_dist4(const float *__restrict__ V, int64_t crow, int D, float eps,
+                                           const float *qreg, const float *__restrict__ qrow, float *out)
+{
+    float acc[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = 0.0f;
+    const float *v = V + crow * (DT > 0 ? DT : D);
+    if constexpr (DT > 0) {
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                float d = (v[i * DT + k] - qreg[k]) + eps;
+                acc[i] = __builtin_fmaf(d, d, acc[i]);
+            }
+        }
+    } else {
+        for (int k = 0; k < D; ++k) {
+            float qk = qrow[k];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                float d = (v[(int64_t)i * D + k] - qk) + eps;
+                acc[i] = __builtin_fmaf(d, d, acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) out[i] = __builtin_sqrtf(acc[i]);
+}
+
+// all n clip distances of one video into the wave's LDS column ds[c*64 + lane]
+template <int DT>
+__device__ __forceinline__ void video_distances(const float *__restrict__ V, int c0, int n, int D, float eps,
+                                                const float *qreg, const float *__restrict__ qrow, float *ds,
+                                                int lane)
+{
+    int c = 0;
+    for (; c + 4 <= n; c += 4) {
+        float d[4];
+        clip_dist4<DT, 4>(V, c0 + c, D, eps, qreg, qrow, d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ds[(c + i) * 64 + lane] = d[i];
+    }
+    for (; c < n; ++c) {
+        float d[1];
+        clip_dist4<DT, 1>(V, c0 + c, D, eps, qreg, qrow, d);
+        ds[c * 64 + lane] = d[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave-cooperative bitonic sort of KPL*64 keys, element e = i*64 + lane, ascending
+// ------------------------------------------------------------------------------------------------
+template <int KPL>
+__device__ __forceinline__ void wave_sort(unsigned long long (&key)[KPL], int lane)
+{
+    constexpr int CAP = KPL * 64;
+#pragma unroll
+    for (int size = 2; size <= CAP; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            if (stride >= 64) {
+                const int j = stride >> 6;
+#pragma unroll
+                for (int i = 0; i < KPL; ++i) {
+                    if ((i & j) == 0) {
+                        const bool asc = size >= CAP ? true : ((i & (size >> 6)) == 0);
+                        unsigned long long a = key[i], b = key[i | j];
+                        unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
+                        key[i] = asc ? lo : hi;
+                        key[i | j] = asc ? hi : lo;
+                    }
+                }
+            } else {
+                const bool lower = (lane & stride) == 0;
+#pragma unroll
+                for (int i = 0; i < KPL; ++i) {
+                    bool asc;
+                    if (size >= CAP) asc = true;
+                    else if (size >= 64) asc = (i & (size >> 6)) == 0;
+                    else asc = (lane & size) == 0;
+                    unsigned long long other = __shfl_xor(key[i], stride, 64);
+                    unsigned long long mn = key[i] < other ? key[i] : other;
+                    unsigned long long mx = key[i] < other ? other : key[i];
+                    key[i] = (lower == asc) ? mn : mx;
+                }
+            }
+        }
+    }
+}
+
+template <int KPL>
+__device__ __forceinline__ unsigned long long key_at(const unsigned long long (&key)[KPL], int e)
+{
+    unsigned long long r = 0;
+    const int i = e >> 6, l = e & 63;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j)
+        if (j == i) r = __shfl(key[j], l, 64);
+    return r;
+}
+
+// compact the candidate buffer of lane L (wave-uniform): keep the k smallest keys, sorted.
+// returns the new count; *thr_out = k-th smallest key when at least k keys exist.
+template <int KPL>
+__device__ __forceinline__ int compact_buffer(unsigned long long *base, int cnt, int k, int lane,
+                                              unsigned long long *thr_out)
+{
+    unsigned long long key[KPL];
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        int e = i * 64 + lane;
+        key[i] = e < cnt ? base[e] : KEY_MAX;
+    }
+    wave_sort<KPL>(key, lane);
+    const int keep = cnt < k ? cnt : k;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        int e = i * 64 + lane;
+        if (e < keep) base[e] = key[i];
+    }
+    if (cnt >= k) *thr_out = key_at<KPL>(key, k - 1);
+    return keep;
+}
+
+// read-only inputs are separate `const __restrict__` kernel parameters (not members of this struct):
+// only then does the backend know they are never written by the kernel and may use the (non-coherent)
+// scalar cache for the wave-uniform V / offset loads.
+struct ScoreArgs {
+    const float *Q; int64_t Nq;
+    const float *V; const int32_t *clip_off; const int64_t *mom_off;
+    int Nv, D; float eps;
+    int64_t id_base;
+    int k;
+    int num_rank;                                     // rank keys per query (0..MAX_RANK)
+    const float *rank_dist; const int64_t *rank_idx; int64_t *count_lt;
+    float *scores; int64_t total_moments;            // dense mode
+    unsigned long long *buf; int *buf_cnt;            // [tasks*64][CAP], [tasks*64]
+    unsigned long long *thr_global;                   // [Nq]
+    int num_groups, num_chunks;
+    int ds_rows;                                      // LDS rows per wave = max clips per video
+};
+
+// MODE 0: dense scores; MODE 1: fused top-k and/or rank counting
+template <int DT, int MODE, int KPL>
+__global__ __launch_bounds__(256) void score_kernel(const float *__restrict__ Qp, const float *__restrict__ Vp,
+                                                    const int32_t *__restrict__ clip_off,
+                                                    const int64_t *__restrict__ mom_off,
+                                                    const float *__restrict__ rank_dist,
+                                                    const int64_t *__restrict__ rank_idx, ScoreArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CAP = KPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int task = blockIdx.x * 4 + wave;
+    if (task >= a.num_groups * a.num_chunks) return;
+    const int chunk = task / a.num_groups, group = task - chunk * a.num_groups;
+    float *ds = smem + (size_t)wave * a.ds_rows * 64;
+
+    const int64_t qi = (int64_t)group * 64 + lane;
+    const bool active = qi < a.Nq;
+    const int64_t qrow_i = active ? qi : a.Nq - 1;
+    const float *__restrict__ qrow = Qp + qrow_i * a.D;
+    float qreg[DT > 0 ? DT : 1];
+    if constexpr (DT > 0) {
+#pragma unroll
+        for (int kk = 0; kk < DT; ++kk) qreg[kk] = qrow[kk];
+    }
+
+    const int v0 = (int)((int64_t)a.Nv * chunk / a.num_chunks);
+    const int v1 = (int)((int64_t)a.Nv * (chunk + 1) / a.num_chunks);
+
+    // selection state (MODE 1)
+    unsigned long long thr = KEY_MAX, kstar[MAX_RANK] = {0, 0, 0, 0};
+    int cnt = 0, nlt[MAX_RANK] = {0, 0, 0, 0};
+    unsigned long long *mybuf = nullptr;
+    const bool want_topk = MODE == 1 && a.k > 0;
+    const bool want_rank = MODE == 1 && rank_dist != nullptr;
+    if (MODE == 1) {
+        if (want_topk) mybuf = a.buf + ((size_t)task * 64 + lane) * CAP;
+        if (want_rank && active) {
+#pragma unroll
+            for (int r = 0; r < MAX_RANK; ++r)
+                if (r < a.num_rank) kstar[r] = make_key(rank_dist[r * a.Nq + qi], (unsigned)rank_idx[r * a.Nq + qi]);
+        }
+    }
+
+    for (int v = v0; v < v1; ++v) {
+        const int c0 = clip_off[v], n = clip_off[v + 1] - c0;
+        const int64_t mbase = mom_off[v];
+        video_distances<DT>(Vp, c0, n, a.D, a.eps, qreg, qrow, ds, lane);
+        if (MODE == 1 && want_topk && active) {    // pick up thresholds published by other waves
+            unsigned long long g = __hip_atomic_load(a.thr_global + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            thr = g < thr ? g : thr;
+        }
+        for (int s = 0; s < n; ++s) {
+            if (MODE == 1 && want_topk) {
+                // this start can append up to n - s keys per lane: make room first (wave-uniform)
+                unsigned long long need = __ballot(cnt > CAP - (n - s));
+                while (need) {
+                    const int L = __builtin_ctzll(need);
+                    need &= need - 1;
+                    __threadfence_block();
+                    unsigned long long nthr = KEY_MAX;
+                    const int cL = __shfl(cnt, L, 64);
+                    unsigned long long *bL = a.buf + ((size_t)task * 64 + L) * CAP;
+                    const int keep = compact_buffer<KPL>(bL, cL, a.k, lane, &nthr);
+                    __threadfence_block();
+                    if (lane == L) {
+                        cnt = keep;
+                        if (nthr < thr) {
+                            thr = nthr;
+                            __hip_atomic_fetch_min(a.thr_global + qi, thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+            float sum = 0.0f;
+            for (int e = s; e < n; ++e) {
+                const float de = ds[e * 64 + lane];
+                sum = e == s ? de : sum + de;
+                const float sc = sum / (float)(e - s + 1);
+                const int local = moment_index(n, s, e);
+                if (MODE == 0) {
+                    if (active) a.scores[qi * a.total_moments + mbase + local] = sc;
+                } else {
+                    const unsigned long long key = make_key(sc, (unsigned)(a.id_base + mbase + local));
+                    if (want_rank) {
+#pragma unroll
+                        for (int r = 0; r < MAX_RANK; ++r) nlt[r] += key < kstar[r] ? 1 : 0;   // kstar = 0 when unused
+                    }
+                    if (want_topk && active && key < thr) mybuf[cnt++] = key;
+                }
+            }
+        }
+    }
+
+    if (MODE == 1) {
+        if (want_rank && active) {
+#pragma unroll
+            for (int r = 0; r < MAX_RANK; ++r)
+                if (r < a.num_rank && nlt[r])
+                    atomicAdd(reinterpret_cast<unsigned long long *>(a.count_lt + r * a.Nq + qi), (unsigned long long)nlt[r]);
+        }
+        if (want_topk) {
+            // final: every lane's buffer sorted and cut to k (the merge kernel reads the first cnt keys)
+            // cut every over-full buffer to its k best (the merge kernel sorts, so order is free)
+            unsigned long long need = __ballot(cnt > a.k);
+            while (need) {
+                const int L = __builtin_ctzll(need);
+                need &= need - 1;
+                __threadfence_block();
+                unsigned long long nthr = KEY_MAX;
+                const int cL = __shfl(cnt, L, 64);
+                unsigned long long *bL = a.buf + ((size_t)task * 64 + L) * CAP;
+                const int keep = compact_buffer<KPL>(bL, cL, a.k, lane, &nthr);
+                if (lane == L) cnt = keep;
+            }
+            __threadfence_block();
+            a.buf_cnt[(size_t)task * 64 + lane] = active ? cnt : 0;
+        }
+    }
+}
+
+// one wave per query: merge the per-chunk sorted lists into the final top-k
+template <int KPL>
+__global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned long long *__restrict__ buf,
+                                                               const int *__restrict__ buf_cnt, int num_groups,
+                                                               int num_chunks, int64_t Nq, int k,
+                                                               float *__restrict__ out_dist,
+                                                               int64_t *__restrict__ out_idx)
+{
+    constexpr int CAP = KPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Nq) return;
+    const int group = (int)(q >> 6), ql = (int)(q & 63);
+    unsigned long long key[KPL];
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) key[i] = KEY_MAX;
+    int fill = 0;         // key elements [0, fill) hold candidates, the rest KEY_MAX
+    for (int ch = 0; ch < num_chunks; ++ch) {
+        const size_t slot = ((size_t)ch * num_groups + group) * 64 + ql;
+        const int c = buf_cnt[slot];
+        const unsigned long long *src = buf + slot * CAP;
+        int off = 0;
+        while (off < c) {
+            if (fill == CAP) {            // full: sort, keep the k best (k < CAP, so this frees room)
+                wave_sort<KPL>(key, lane);
+#pragma unroll
+                for (int i = 0; i < KPL; ++i)
+                    if (i * 64 + lane >= k) key[i] = KEY_MAX;
+                fill = k;
+            }
+            const int room = CAP - fill, take = (c - off) < room ? (c - off) : room;
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                int e = i * 64 + lane;
+                if (e >= fill && e < fill + take) key[i] = src[off + e - fill];
+            }
+            fill += take; off += take;
+        }
+    }
+    wave_sort<KPL>(key, lane);
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        int e = i * 64 + lane;
+        if (e < k) {
+            const bool ok = key[i] != KEY_MAX;
+            out_dist[q * k + e] = ok ? __uint_as_float((unsigned)(key[i] >> 32)) : __builtin_inff();
+            out_idx[q * k + e] = ok ? (int64_t)(key[i] & 0xffffffffull) : -1;
+        }
+    }
+}
+
+// merge G shard lists given as (dist, idx) arrays: [G, Nq, k] -> [Nq, k]   (after the all-gather, 8e)
+template <int KPL>
+__global__ __launch_bounds__(256) void topk_merge_parts_kernel(const float *__restrict__ pd,
+                                                               const int64_t *__restrict__ pi, int G, int64_t Nq,
+                                                               int k, float *__restrict__ out_dist,
+                                                               int64_t *__restrict__ out_idx)
+{
+    constexpr int CAP = KPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Nq) return;
+    unsigned long long key[KPL];
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) key[i] = KEY_MAX;
+    int fill = 0;
+    for (int g = 0; g < G; ++g) {
+        const float *d = pd + ((int64_t)g * Nq + q) * k;
+        const int64_t *ix = pi + ((int64_t)g * Nq + q) * k;
+        int off = 0;
+        while (off < k) {
+            if (fill == CAP) {
+                wave_sort<KPL>(key, lane);
+#pragma unroll
+                for (int i = 0; i < KPL; ++i)
+                    if (i * 64 + lane >= k) key[i] = KEY_MAX;
+                fill = k;
+            }
+            const int room = CAP - fill, take = (k - off) < room ? (k - off) : room;
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                int e = i * 64 + lane;
+                if (e >= fill && e < fill + take) {
+                    int64_t id = ix[off + e - fill];
+                    key[i] = id < 0 ? KEY_MAX : make_key(d[off + e - fill], (unsigned)id);
+                }
+            }
+            fill += take; off += take;
+        }
+    }
+    wave_sort<KPL>(key, lane);
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        int e = i * 64 + lane;
+        if (e < k) {
+            const bool ok = key[i] != KEY_MAX;
+            out_dist[q * k + e] = ok ? __uint_as_float((unsigned)(key[i] >> 32)) : __builtin_inff();
+            out_idx[q * k + e] = ok ? (int64_t)(key[i] & 0xffffffffull) : -1;
+        }
+    }
+}
+
+// each query against its own video (evaluate_single.py:48-53): V is per-lane here, plain loads
+__global__ __launch_bounds__(64) void score_own_kernel(const float *__restrict__ Q, int64_t Nq,
+                                                       const float *__restrict__ V,
+                                                       const int32_t *__restrict__ clip_off,
+                                                       const int32_t *__restrict__ own, int D, float eps, int Mmax,
+                                                       float *__restrict__ scores)
+{
+    extern __shared__ __attribute__((aligned(16))) float ds[];
+    const int lane = threadIdx.x;
+    const int64_t q = (int64_t)blockIdx.x * 64 + lane;
+    if (q >= Nq) return;
+    const int v = own[q], c0 = clip_off[v], n = clip_off[v + 1] - c0;
+    for (int m = 0; m < Mmax; ++m) scores[q * Mmax + m] = __builtin_inff();
+    for (int c = 0; c < n; ++c) {
+        float acc = 0.0f;
+        for (int k = 0; k < D; ++k) {
+            float d = (V[(int64_t)(c0 + c) * D + k] - Q[q * D + k]) + eps;
+            acc = __builtin_fmaf(d, d, acc);
+        }
+        ds[c * 64 + lane] = __builtin_sqrtf(acc);
+    }
+    for (int s = 0; s < n; ++s) {
+        float sum = 0.0f;
+        for (int e = s; e < n; ++e) {
+            const float de = ds[e * 64 + lane];
+            sum = e == s ? de : sum + de;
+            scores[q * Mmax + moment_index(n, s, e)] = sum / (float)(e - s + 1);
+        }
+    }
+}
+
+static void plan_tasks(int64_t Nq, int Nv, int *groups, int *chunks)
+{
+    int g = (int)cdiv(Nq, 64);
+    // aim for ~12 waves per CU on 256 CUs; never more chunks than videos
+    int64_t want = cdiv(3072, g);
+    int c = (int)(want < 1 ? 1 : want);
+    if (c > Nv) c = Nv < 1 ? 1 : Nv;
+    if (c > 1024) c = 1024;
+    *groups = g;
+    *chunks = c;
+}
+static int kpl_for(int k) { return k <= 128 ? 4 : 8; }
+
+struct TopkWs { unsigned long long *buf; int *cnt; unsigned long long *thr; size_t total; };
+static TopkWs carve_topk(void *base, int64_t Nq, int Nv, int k)
+{
+    TopkWs w{};
+    int g, c;
+    plan_tasks(Nq, Nv, &g, &c);
+    size_t tasks = (size_t)g * c, cap = (size_t)kpl_for(k) * 64, off = 0;
+    auto take = [&](size_t bytes) { char *p = static_cast<char *>(base) + off; off += align_up(bytes, 256); return p; };
+    w.thr = reinterpret_cast<unsigned long long *>(take((size_t)Nq * 8));
+    w.cnt = reinterpret_cast<int *>(take(tasks * 64 * 4));
+    w.buf = reinterpret_cast<unsigned long long *>(take(k > 0 ? tasks * 64 * cap * 8 : 0));
+    w.total = off;
+    return w;
+}
+
+template <int MODE>
+static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st)
+{
+    const int tasks = a.num_groups * a.num_chunks;
+    const size_t lds = (size_t)4 * a.ds_rows * 64 * sizeof(float);
+    dim3 grid((unsigned)cdiv(tasks, 4)), block(256);
+#define VFR_LAUNCH(DT, KPL)                                                                              \
+    hipLaunchKernelGGL((score_kernel<DT, MODE, KPL>), grid, block, lds, st, a.Q, a.V, a.clip_off, a.mom_off, \
+                       a.rank_dist, a.rank_idx, a)
+    if (a.D == 100) { if (kpl == 4) VFR_LAUNCH(100, 4); else VFR_LAUNCH(100, 8); }
+    else            { if (kpl == 4) VFR_LAUNCH(0, 4);   else VFR_LAUNCH(0, 8); }
+#undef VFR_LAUNCH
+    VFR_CHECK_LAUNCH("score_kernel");
+    return VFR_OK;
+}
+
+}  // namespace vfr
+
+extern "C" {
+
+int vfr_score_moments_f32(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets,
+                          const int64_t *moment_offsets, int Nv, int max_clips, int64_t total_moments, int D,
+                          float eps, float *scores, vfr_stream_t stream)
+{
+    VFR_REQUIRE(Q && V && clip_offsets && moment_offsets && scores && Nq >= 0 && Nv >= 0 && D > 0 && total_moments >= 0,
+                VFR_EINVAL, "vfr_score_moments_f32: bad argument");
+    VFR_REQUIRE(max_clips <= vfr::NMAX_DENSE, VFR_EUNSUPPORTED, "vfr_score_moments_f32: max_clips=%d > %d", max_clips,
+                vfr::NMAX_DENSE);
+    if (Nq == 0 || Nv == 0) return VFR_OK;
+    vfr::ScoreArgs a{};
+    a.Q = Q; a.Nq = Nq; a.V = V; a.clip_off = clip_offsets; a.mom_off = moment_offsets; a.Nv = Nv; a.D = D; a.eps = eps;
+    a.scores = scores; a.total_moments = total_moments; a.ds_rows = max_clips < 1 ? 1 : max_clips;
+    vfr::plan_tasks(Nq, Nv, &a.num_groups, &a.num_chunks);
+    return vfr::launch_score<0>(a, 4, vfr::as_stream(stream));
+}
+
+int vfr_score_own_f32(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets, const int32_t *own,
+                      int max_clips, int D, float eps, int Mmax, float *scores, vfr_stream_t stream)
+{
+    VFR_REQUIRE(Q && V && clip_offsets && own && scores && Nq >= 0 && D > 0 && Mmax >= 0, VFR_EINVAL,
+                "vfr_score_own_f32: bad argument");
+    VFR_REQUIRE(max_clips <= vfr::NMAX_DENSE && Mmax >= max_clips * (max_clips + 1) / 2, VFR_EUNSUPPORTED,
+                "vfr_score_own_f32: max_clips=%d (limit %d) needs Mmax >= %d, got %d", max_clips, vfr::NMAX_DENSE,
+                max_clips * (max_clips + 1) / 2, Mmax);
+    if (Nq == 0) return VFR_OK;
+    hipLaunchKernelGGL(vfr::score_own_kernel, dim3((unsigned)vfr::cdiv(Nq, 64)), dim3(64),
+                       (size_t)max_clips * 64 * sizeof(float), vfr::as_stream(stream), Q, Nq, V, clip_offsets, own, D,
+                       eps, Mmax, scores);
+    VFR_CHECK_LAUNCH("score_own_kernel");
+    return VFR_OK;
+}
+
+size_t vfr_score_topk_workspace_bytes(int64_t Nq, int Nv, int k)
+{
+    if (Nq < 0 || Nv < 0 || k < 0) return 0;
+    return vfr::carve_topk(nullptr, Nq, Nv, k).total;
+}
+
+int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets,
+                       const int64_t *moment_offsets, int Nv, int total_clips, int max_clips, int D, float eps,
+                       int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
+                       const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, void *workspace,
+                       size_t workspace_bytes, vfr_stream_t stream)
+{
+    (void)total_clips;
+    VFR_REQUIRE(num_rank >= 0 && num_rank <= vfr::MAX_RANK, VFR_EUNSUPPORTED, "vfr_score_topk_f32: num_rank=%d > %d",
+                num_rank, vfr::MAX_RANK);
+    if (num_rank == 0) { rank_dist = nullptr; rank_idx = nullptr; }
+    VFR_REQUIRE(Q && V && clip_offsets && moment_offsets && Nq >= 0 && Nv >= 0 && D > 0 && k >= 0 && id_base >= 0,
+                VFR_EINVAL, "vfr_score_topk_f32: bad argument");
+    VFR_REQUIRE(k == 0 || (out_dist && out_idx), VFR_EINVAL, "vfr_score_topk_f32: k > 0 needs out_dist/out_idx");
+    VFR_REQUIRE(num_rank == 0 || (rank_dist && rank_idx && count_lt), VFR_EINVAL,
+                "vfr_score_topk_f32: num_rank > 0 needs rank_dist, rank_idx and count_lt");
+    VFR_REQUIRE(max_clips <= vfr::NMAX_FUSED, VFR_EUNSUPPORTED, "vfr_score_topk_f32: max_clips=%d > %d", max_clips,
+                vfr::NMAX_FUSED);
+    VFR_REQUIRE(k <= 448, VFR_EUNSUPPORTED, "vfr_score_topk_f32: k=%d > 448", k);
+    if (Nq == 0) return VFR_OK;
+    hipStream_t st = vfr::as_stream(stream);
+    VFR_REQUIRE(workspace && workspace_bytes >= vfr_score_topk_workspace_bytes(Nq, Nv, k), VFR_EWORKSPACE,
+                "vfr_score_topk_f32: workspace %zu < %zu bytes", workspace_bytes,
+                vfr_score_topk_workspace_bytes(Nq, Nv, k));
+    vfr::TopkWs w = vfr::carve_topk(workspace, Nq, Nv, k);
+    vfr::ScoreArgs a{};
+    a.Q = Q; a.Nq = Nq; a.V = V; a.clip_off = clip_offsets; a.mom_off = moment_offsets; a.Nv = Nv; a.D = D; a.eps = eps;
+    a.id_base = id_base; a.k = k; a.num_rank = num_rank; a.rank_dist = rank_dist; a.rank_idx = rank_idx; a.count_lt = count_lt;
+    a.buf = w.buf; a.buf_cnt = w.cnt; a.thr_global = w.thr; a.ds_rows = max_clips < 1 ? 1 : max_clips;
+    vfr::plan_tasks(Nq, Nv, &a.num_groups, &a.num_chunks);
+    const int kpl = vfr::kpl_for(k);
+    if (Nv > 0) {
+        if (k > 0 && hipMemsetAsync(w.thr, 0xFF, (size_t)Nq * 8, st) != hipSuccess)
+            return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: hipMemsetAsync failed");
+        if (int rc = vfr::launch_score<1>(a, kpl, st)) return rc;
+    } else if (k > 0) {
+        if (hipMemsetAsync(w.cnt, 0, (size_t)a.num_groups * a.num_chunks * 64 * 4, st) != hipSuccess)
+            return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: hipMemsetAsync failed");
+    }
+    if (k > 0) {
+        dim3 grid((unsigned)vfr::cdiv(Nq, 4)), block(256);
+        if (kpl == 4)
+            hipLaunchKernelGGL((vfr::topk_merge_tasks_kernel<4>), grid, block, 0, st, w.buf, w.cnt, a.num_groups,
+                               a.num_chunks, Nq, k, out_dist, out_idx);
+        else
+            hipLaunchKernelGGL((vfr::topk_merge_tasks_kernel<8>), grid, block, 0, st, w.buf, w.cnt, a.num_groups,
+                               a.num_chunks, Nq, k, out_dist, out_idx);
+        VFR_CHECK_LAUNCH("topk_merge_tasks_kernel");
+    }
+    return VFR_OK;
+}
+
+int vfr_topk_merge_f32(const float *part_dist, const int64_t *part_idx, int G, int64_t Nq, int k, float *out_dist,
+                       int64_t *out_idx, vfr_stream_t stream)
+{
+    VFR_REQUIRE(part_dist && part_idx && out_dist && out_idx && G > 0 && Nq >= 0 && k > 0, VFR_EINVAL,
+                "vfr_topk_merge_f32: bad argument");
+    VFR_REQUIRE(k <= 448, VFR_EUNSUPPORTED, "vfr_topk_merge_f32: k=%d > 448", k);
+    if (Nq == 0) return VFR_OK;
+    dim3 grid((unsigned)vfr::cdiv(Nq, 4)), block(256);
+    if (vfr::kpl_for(k) == 4)
+        hipLaunchKernelGGL((vfr::topk_merge_parts_kernel<4>), grid, block, 0, vfr::as_stream(stream), part_dist,
+                           part_idx, G, Nq, k, out_dist, out_idx);
+    else
+        hipLaunchKernelGGL((vfr::topk_merge_parts_kernel<8>), grid, block, 0, vfr::as_stream(stream), part_dist,
+                           part_idx, G, Nq, k, out_dist, out_idx);
+    VFR_CHECK_LAUNCH("topk_merge_parts_kernel");
+    return VFR_OK;
+}
+
+}  // extern "C"

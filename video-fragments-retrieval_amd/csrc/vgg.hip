@@ -1,0 +1,239 @@
+// a1 + a2: per-frame RGB feature extractor = ImageNet normalisation (get_rgb_features.py:64-69) +
+// torchvision VGG-19 "E" features / avgpool / classifier[0..4] (get_rgb_features.py:122-126).
+//
+// Canonical arithmetic (matches oracle/vfr_oracle.c):
+//   normalise : ((u8 / 255) - mean[c]) / std[c]
+//   conv3x3   : one fma chain per output over k = (cin*3 + ky)*3 + kx ascending (the [Cout,Cin,3,3]
+//               weight layout), zero padding contributes fma(0, w, acc) = acc; + bias; ReLU
+//   maxpool   : max of the 2x2 window;  adaptive avgpool 7x7: row-major window sum / count
+//   fc6 / fc7 : chain GEMM + bias + ReLU (gemm.hip)
+#include "vfr_common.h"
+
+namespace vfr {
+
+__constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
+__constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
+
+__global__ __launch_bounds__(256) void frames_normalize_kernel(const uint8_t *__restrict__ in, int64_t total, int H,
+                                                               int W, float *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // index into TCHW output
+    if (i >= total) return;
+    int x = (int)(i % W);
+    int64_t r = i / W;
+    int y = (int)(r % H); r /= H;
+    int c = (int)(r % 3);
+    int64_t t = r / 3;
+    float v = (float)in[((t * H + y) * W + x) * 3 + c];
+    v = v / 255.0f;
+    v = v - c_mean[c];
+    out[i] = v / c_std[c];
+}
+
+// direct convolution: one thread per output pixel, output channels tiled 8 per thread for input reuse
+constexpr int CO_T = 8;
+__global__ __launch_bounds__(256) void conv3x3_relu_kernel(const float *__restrict__ x, int B, int Cin, int H, int W,
+                                                           const float *__restrict__ w, const float *__restrict__ b,
+                                                           int Cout, float *__restrict__ y)
+{
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over B*H*W
+    const int co0 = blockIdx.y * CO_T;
+    if (pix >= (int64_t)B * H * W) return;
+    const int ox = (int)(pix % W);
+    const int oy = (int)((pix / W) % H);
+    const int n = (int)(pix / ((int64_t)W * H));
+    float acc[CO_T];
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) acc[j] = 0.0f;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float *xp = x + ((int64_t)n * Cin + ci) * H * W;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy + ky - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox + kx - 1;
+                const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const float xv = in ? xp[(int64_t)iy * W + ix] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < CO_T; ++j) {
+                    const int co = co0 + j;
+                    const float wv = co < Cout ? w[(((int64_t)co * Cin + ci) * 3 + ky) * 3 + kx] : 0.0f;
+                    acc[j] = __builtin_fmaf(xv, wv, acc[j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) {
+        const int co = co0 + j;
+        if (co >= Cout) continue;
+        float v = acc[j] + b[co];
+        y[(((int64_t)n * Cout + co) * H + oy) * W + ox] = v > 0.0f ? v : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float *__restrict__ x, int64_t planes, int H, int W,
+                                                       float *__restrict__ y)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * Ho * Wo) return;
+    int ox = (int)(i % Wo);
+    int oy = (int)((i / Wo) % Ho);
+    int64_t p = i / ((int64_t)Wo * Ho);
+    const float *xp = x + p * H * W + (int64_t)(2 * oy) * W + 2 * ox;
+    y[i] = fmaxf(fmaxf(xp[0], xp[1]), fmaxf(xp[W], xp[W + 1]));
+}
+
+__global__ __launch_bounds__(256) void adaptive_avgpool7_kernel(const float *__restrict__ x, int64_t planes, int H,
+                                                                int W, float *__restrict__ y)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * 49) return;
+    int ox = (int)(i % 7), oy = (int)((i / 7) % 7);
+    int64_t p = i / 49;
+    int y0 = (oy * H) / 7, y1 = ((oy + 1) * H + 6) / 7, x0 = (ox * W) / 7, x1 = ((ox + 1) * W + 6) / 7;
+    float acc = 0.0f;
+    for (int iy = y0; iy < y1; ++iy)
+        for (int ix = x0; ix < x1; ++ix) acc = acc + x[p * H * W + (int64_t)iy * W + ix];
+    y[i] = acc / (float)((y1 - y0) * (x1 - x0));
+}
+
+static int run_conv(const float *x, int B, int Cin, int H, int W, const float *w, const float *b, int Cout, float *y,
+                    hipStream_t st)
+{
+    dim3 grid((unsigned)cdiv((int64_t)B * H * W, 256), (unsigned)cdiv(Cout, CO_T));
+    hipLaunchKernelGGL(conv3x3_relu_kernel, grid, dim3(256), 0, st, x, B, Cin, H, W, w, b, Cout, y);
+    VFR_CHECK_LAUNCH("conv3x3_relu_kernel");
+    return VFR_OK;
+}
+static int run_maxpool(const float *x, int64_t planes, int H, int W, float *y, hipStream_t st)
+{
+    int64_t n = planes * (H / 2) * (W / 2);
+    if (n == 0) return VFR_OK;
+    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, x, planes, H, W, y);
+    VFR_CHECK_LAUNCH("maxpool2_kernel");
+    return VFR_OK;
+}
+static int run_avgpool(const float *x, int64_t planes, int H, int W, float *y, hipStream_t st)
+{
+    hipLaunchKernelGGL(adaptive_avgpool7_kernel, dim3((unsigned)cdiv(planes * 49, 256)), dim3(256), 0, st, x, planes, H,
+                       W, y);
+    VFR_CHECK_LAUNCH("adaptive_avgpool7_kernel");
+    return VFR_OK;
+}
+
+constexpr int VGG_FRAME_CHUNK = 32;   // frames per pass through the conv stack (bounds the workspace)
+
+struct VggPlan { size_t act_elems; int c_last, h_last, w_last; bool ok; };
+static VggPlan plan_vgg(int chunk, int H, int W, const int *cfg, int ncfg)
+{
+    VggPlan p{0, 3, H, W, true};
+    size_t cur = (size_t)chunk * 3 * H * W;
+    p.act_elems = cur;
+    for (int i = 0; i < ncfg; ++i) {
+        if (cfg[i] > 0) p.c_last = cfg[i];
+        else { if (p.h_last < 2 || p.w_last < 2) p.ok = false; p.h_last /= 2; p.w_last /= 2; }
+        cur = (size_t)chunk * p.c_last * p.h_last * p.w_last;
+        if (cur > p.act_elems) p.act_elems = cur;
+    }
+    if (p.h_last < 1 || p.w_last < 1) p.ok = false;
+    return p;
+}
+
+}  // namespace vfr
+
+extern "C" {
+
+int vfr_frames_normalize_f32(const uint8_t *frames_thwc, int T, int H, int W, float *out_tchw, vfr_stream_t stream)
+{
+    VFR_REQUIRE(frames_thwc && out_tchw && T >= 0 && H > 0 && W > 0, VFR_EINVAL, "vfr_frames_normalize_f32: bad argument");
+    int64_t total = (int64_t)T * 3 * H * W;
+    if (total == 0) return VFR_OK;
+    hipLaunchKernelGGL(vfr::frames_normalize_kernel, dim3((unsigned)vfr::cdiv(total, 256)), dim3(256), 0,
+                       vfr::as_stream(stream), frames_thwc, total, H, W, out_tchw);
+    VFR_CHECK_LAUNCH("frames_normalize_kernel");
+    return VFR_OK;
+}
+
+int vfr_conv3x3_relu_f32(const float *x, int B, int Cin, int H, int W, const float *w, const float *b, int Cout,
+                         float *y, vfr_stream_t stream)
+{
+    VFR_REQUIRE(x && w && b && y && B >= 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, VFR_EINVAL,
+                "vfr_conv3x3_relu_f32: bad argument");
+    if (B == 0) return VFR_OK;
+    return vfr::run_conv(x, B, Cin, H, W, w, b, Cout, y, vfr::as_stream(stream));
+}
+
+int vfr_maxpool2_f32(const float *x, int B, int C, int H, int W, float *y, vfr_stream_t stream)
+{
+    VFR_REQUIRE(x && y && B >= 0 && C > 0 && H > 1 && W > 1, VFR_EINVAL, "vfr_maxpool2_f32: bad argument");
+    return vfr::run_maxpool(x, (int64_t)B * C, H, W, y, vfr::as_stream(stream));
+}
+
+int vfr_adaptive_avgpool7_f32(const float *x, int B, int C, int H, int W, float *y, vfr_stream_t stream)
+{
+    VFR_REQUIRE(x && y && B >= 0 && C > 0 && H > 0 && W > 0, VFR_EINVAL, "vfr_adaptive_avgpool7_f32: bad argument");
+    if (B == 0) return VFR_OK;
+    return vfr::run_avgpool(x, (int64_t)B * C, H, W, y, vfr::as_stream(stream));
+}
+
+size_t vfr_vgg_fc7_workspace_bytes(int T, int H, int W, const int *cfg_host, int ncfg, int fc_dim)
+{
+    if (T < 0 || H <= 0 || W <= 0 || !cfg_host || ncfg <= 0 || fc_dim <= 0) return 0;
+    int chunk = T < vfr::VGG_FRAME_CHUNK ? T : vfr::VGG_FRAME_CHUNK;
+    vfr::VggPlan p = vfr::plan_vgg(chunk, H, W, cfg_host, ncfg);
+    size_t act = vfr::align_up(p.act_elems * sizeof(float), 256);
+    size_t pooled = vfr::align_up((size_t)T * p.c_last * 49 * sizeof(float), 256);
+    size_t h6 = vfr::align_up((size_t)T * fc_dim * sizeof(float), 256);
+    return 2 * act + pooled + h6;
+}
+
+int vfr_vgg_fc7_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *cfg_host, int ncfg,
+                    const float *const *conv_w_host, const float *const *conv_b_host, const float *fc6_w,
+                    const float *fc6_b, const float *fc7_w, const float *fc7_b, int fc_dim, float *out,
+                    void *workspace, size_t workspace_bytes, vfr_stream_t stream)
+{
+    VFR_REQUIRE(frames_thwc && cfg_host && conv_w_host && conv_b_host && fc6_w && fc6_b && fc7_w && fc7_b && out &&
+                    T >= 0 && H > 0 && W > 0 && ncfg > 0 && fc_dim > 0,
+                VFR_EINVAL, "vfr_vgg_fc7_f32: bad argument");
+    if (T == 0) return VFR_OK;
+    const int chunk = T < vfr::VGG_FRAME_CHUNK ? T : vfr::VGG_FRAME_CHUNK;
+    vfr::VggPlan p = vfr::plan_vgg(chunk, H, W, cfg_host, ncfg);
+    VFR_REQUIRE(p.ok, VFR_EUNSUPPORTED, "vfr_vgg_fc7_f32: %dx%d frames too small for %d pooling stages", H, W, ncfg);
+    VFR_REQUIRE(workspace && workspace_bytes >= vfr_vgg_fc7_workspace_bytes(T, H, W, cfg_host, ncfg, fc_dim),
+                VFR_EWORKSPACE, "vfr_vgg_fc7_f32: workspace %zu < %zu bytes", workspace_bytes,
+                vfr_vgg_fc7_workspace_bytes(T, H, W, cfg_host, ncfg, fc_dim));
+    hipStream_t st = vfr::as_stream(stream);
+    char *base = static_cast<char *>(workspace);
+    const size_t act = vfr::align_up(p.act_elems * sizeof(float), 256);
+    float *bufA = reinterpret_cast<float *>(base), *bufB = reinterpret_cast<float *>(base + act);
+    float *pooled = reinterpret_cast<float *>(base + 2 * act);
+    float *h6 = reinterpret_cast<float *>(base + 2 * act + vfr::align_up((size_t)T * p.c_last * 49 * sizeof(float), 256));
+    const int K6 = p.c_last * 49;
+
+    for (int t0 = 0; t0 < T; t0 += chunk) {
+        const int bt = (T - t0) < chunk ? (T - t0) : chunk;
+        if (int rc = vfr_frames_normalize_f32(frames_thwc + (size_t)t0 * H * W * 3, bt, H, W, bufA, stream)) return rc;
+        float *cur = bufA, *nxt = bufB;
+        int c = 3, h = H, w = W, conv = 0;
+        for (int i = 0; i < ncfg; ++i) {
+            if (cfg_host[i] > 0) {
+                if (int rc = vfr::run_conv(cur, bt, c, h, w, conv_w_host[conv], conv_b_host[conv], cfg_host[i], nxt, st))
+                    return rc;
+                c = cfg_host[i];
+                ++conv;
+            } else {
+                if (int rc = vfr::run_maxpool(cur, (int64_t)bt * c, h, w, nxt, st)) return rc;
+                h /= 2; w /= 2;
+            }
+            float *tmp = cur; cur = nxt; nxt = tmp;
+        }
+        if (int rc = vfr::run_avgpool(cur, (int64_t)bt * c, h, w, pooled + (size_t)t0 * K6, st)) return rc;
+    }
+    if (int rc = vfr_linear_f32(pooled, T, K6, fc6_w, fc6_b, fc_dim, 1, h6, stream)) return rc;
+    return vfr_linear_f32(h6, T, fc_dim, fc7_w, fc7_b, fc_dim, 1, out, stream);
+}
+
+}  // extern "C"

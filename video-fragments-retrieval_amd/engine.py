@@ -1,0 +1,320 @@
+"""Batched retrieval engine under ``evaluate`` / ``evaluate_single`` / ``bench.py``.
+
+The reference scores one (query, video) pair per Python iteration (``model/evaluate.py:42-80``).  Here a
+corpus (or one rank's shard of it) is a ``CorpusShard``: its clip embeddings stay resident in HBM and a
+query batch is answered by three launches -- own-video scores (for ground truth), fused scoring + top-k +
+rank counting, merge -- with one exchange step when the corpus is sharded over ranks:
+
+    rank r holds videos [lo_r, hi_r)  (contiguous in iteration order, so global moment ids are unchanged)
+    best-GT key   : all_reduce(MIN) of the packed (distance, id) key  (only the owner rank has a finite one)
+    rank counts   : all_reduce(SUM) of count_lt
+    top-k         : all_gather of the per-shard [Nq, k] lists, then vfr_topk_merge
+
+``ops`` is the provider of the device arithmetic; the product default is ``HipOps`` (libvfr.so).  Tests of
+the multi-rank plumbing on CPU-only machines inject their own provider.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from .utils import generate_moments, get_iou
+
+KEY_INF = (0x7F800000 << 32) | 0xFFFFFFFF      # key of (+inf, max id): "no ground-truth-positive moment here"
+
+
+class HipOps:
+    """Device arithmetic through the C ABI (``_vfr``).  Raises if libvfr.so or the GPU is missing."""
+
+    def __init__(self):
+        from . import _vfr
+        _vfr.lib()
+        self.v = _vfr
+
+    def make_bank(self, emb, clip_off, id_base):
+        return self.v.VideoBank(emb, clip_off, id_base)
+
+    def encode_clips(self, model, seg, ctx, clip_off):
+        return model.encode_clips(seg, ctx, clip_off)
+
+    def encode_queries(self, model, tokens):
+        return model.encode_queries(tokens)
+
+    def score_own(self, Q, bank, own_local):
+        return self.v.score_own(Q, bank, own_local)
+
+    def score_topk(self, Q, bank, k, rank_dist, rank_idx, workspace=None):
+        return self.v.score_topk(Q, bank, k, rank_dist, rank_idx, workspace=workspace)
+
+    def topk_merge(self, part_dist, part_idx):
+        return self.v.topk_merge(part_dist, part_idx)
+
+
+def shard_range(num_videos: int, rank: int, world: int):
+    """Contiguous, balanced split of the video iteration order."""
+    return (num_videos * rank) // world, (num_videos * (rank + 1)) // world
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+@dataclass
+class CorpusShard:
+    bank: object                 # ops.make_bank(...) result: clip embeddings + CSR offsets on the device
+    lo: int                      # first global video index of this shard
+    hi: int
+    counts_all: np.ndarray       # clips per video for the WHOLE corpus (host)
+    mom_off_all: np.ndarray      # [Nv_all + 1] int64 global moment offsets (host)
+    device: torch.device
+
+    @property
+    def num_videos_all(self):
+        return len(self.counts_all)
+
+
+def build_corpus(model, feature_bank, device, ops=None, rank=0, world=1) -> CorpusShard:
+    """Encode this rank's contiguous slice of ``feature_bank`` (``data.FeatureBank`` on the host or device)."""
+    ops = ops or HipOps()
+    off_all = feature_bank.clip_off.cpu().numpy().astype(np.int64)
+    counts = np.diff(off_all)
+    mom_off_all = np.concatenate([[0], np.cumsum(counts * (counts + 1) // 2)]).astype(np.int64)
+    lo, hi = shard_range(len(counts), rank, world)
+    c0, c1 = int(off_all[lo]), int(off_all[hi])
+    seg = feature_bank.seg[c0:c1].to(device)
+    ctx = feature_bank.ctx[lo:hi].to(device)
+    clip_off = torch.from_numpy((off_all[lo:hi + 1] - c0).astype(np.int32)).to(device)
+    emb = ops.encode_clips(model, seg, ctx, clip_off)
+    bank = ops.make_bank(emb, clip_off, int(mom_off_all[lo]))
+    return CorpusShard(bank, lo, hi, counts, mom_off_all, torch.device(device))
+
+
+def corpus_from_embeddings(emb, counts, device, ops=None, rank=0, world=1) -> CorpusShard:
+    """Same, from precomputed clip embeddings [sum n, D] of the whole corpus (per-item iterator API)."""
+    ops = ops or HipOps()
+    counts = np.asarray(counts, np.int64)
+    off_all = np.concatenate([[0], np.cumsum(counts)])
+    mom_off_all = np.concatenate([[0], np.cumsum(counts * (counts + 1) // 2)]).astype(np.int64)
+    lo, hi = shard_range(len(counts), rank, world)
+    c0, c1 = int(off_all[lo]), int(off_all[hi])
+    clip_off = torch.from_numpy((off_all[lo:hi + 1] - c0).astype(np.int32)).to(device)
+    bank = ops.make_bank(emb[c0:c1].to(device).contiguous(), clip_off, int(mom_off_all[lo]))
+    return CorpusShard(bank, lo, hi, counts, mom_off_all, torch.device(device))
+
+
+def encode_queries(model, tokens, device, ops=None, rank=0, world=1):
+    """Query embeddings for the whole batch; with world > 1 each rank encodes a slice and they are gathered."""
+    ops = ops or HipOps()
+    dist = _dist() if world > 1 else None
+    if dist is None:
+        return ops.encode_queries(model, tokens.to(device))
+    Nq = tokens.shape[0]
+    per = -(-Nq // world)
+    lo = min(rank * per, Nq)
+    hi = min(lo + per, Nq)
+    mine = tokens[lo:hi]
+    if mine.shape[0] < per:                                   # pad so every rank gathers equal chunks
+        mine = torch.cat([mine, tokens.new_zeros((per - mine.shape[0], tokens.shape[1]))])
+    q = ops.encode_queries(model, mine.to(device))
+    parts = [torch.empty_like(q) for _ in range(world)]
+    dist.all_gather(parts, q)
+    return torch.cat(parts)[:Nq].contiguous()
+
+
+def gt_label_table(times, counts_own, thresholds, strict=True):
+    """labels[r, q, m] = 1 iff >= 2 annotators have IoU (>, or >= when not strict) thresholds[r] with local
+    moment m of the query's own video (``model/evaluate.py:59-62``; ``main.py:161`` uses >=).  Host numpy."""
+    nmax = int(max(counts_own)) if len(counts_own) else 0
+    Mmax = nmax * (nmax + 1) // 2
+    labels = np.zeros((len(thresholds), len(times), Mmax), dtype=bool)
+    spans = {n: np.asarray(generate_moments(n), np.int64).reshape(-1, 2) for n in set(int(c) for c in counts_own)}
+    for q, (t, n) in enumerate(zip(times, counts_own)):
+        mom = spans[int(n)]
+        t = np.asarray(t)
+        inter = np.maximum(np.minimum(t[None, :, 1], mom[:, None, 1]) + 1 - np.maximum(t[None, :, 0], mom[:, None, 0]), 0)
+        union = np.maximum(t[None, :, 1], mom[:, None, 1]) + 1 - np.minimum(t[None, :, 0], mom[:, None, 0])
+        iou = inter / union                                                   # [M, annotators], float64 like get_iou
+        for r, thr in enumerate(thresholds):
+            hit = (iou > thr) if strict else (iou >= thr)
+            labels[r, q, :len(mom)] = hit.sum(axis=1) >= 2
+    return labels
+
+
+def _pack_key(dist_t: torch.Tensor, idx_t: torch.Tensor) -> torch.Tensor:
+    """(fp32 distance >= 0, id < 2^32) -> int64 key whose signed order is the (distance, id) order."""
+    bits = dist_t.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    return (bits << 32) | (idx_t.to(torch.int64) & 0xFFFFFFFF)
+
+
+def _unpack_key(key: torch.Tensor):
+    bits = (key >> 32).to(torch.int32)
+    return bits.view(torch.float32), key & 0xFFFFFFFF
+
+
+def best_positive_keys(shard: CorpusShard, Q, own_global, labels, ops, world=1):
+    """Per (threshold, query): key of the best ground-truth-positive moment = min over positives of
+    (score, global id).  Only the rank that owns the query's video can see it; others contribute KEY_INF."""
+    device = shard.device
+    own = np.asarray(own_global, np.int64)
+    local = (own >= shard.lo) & (own < shard.hi)
+    R, Nq, Mmax = labels.shape
+    keys = torch.full((R, Nq), KEY_INF, dtype=torch.int64, device=device)
+    if local.any() and Mmax > 0:
+        sel = np.nonzero(local)[0]
+        sel_t = torch.from_numpy(sel).to(device)
+        own_local = torch.from_numpy((own[sel] - shard.lo).astype(np.int32)).to(device)
+        sc = ops.score_own(Q[sel_t].contiguous(), shard.bank, own_local)          # [n_sel, Mloc], +inf padded
+        Mloc = sc.shape[1]
+        lab = torch.from_numpy(labels[:, sel, :Mloc]).to(device)                  # [R, n_sel, Mloc]
+        base = torch.from_numpy(shard.mom_off_all[own[sel]]).to(device)           # global id of local moment 0
+        ids = base[:, None] + torch.arange(Mloc, device=device)[None, :]
+        k = _pack_key(sc, ids)                                                    # [n_sel, Mloc]
+        k = torch.where(lab, k[None].expand(R, -1, -1), torch.full_like(k, KEY_INF)[None].expand(R, -1, -1))
+        keys[:, sel_t] = k.min(dim=2).values
+    dist = _dist() if world > 1 else None
+    if dist is not None:
+        dist.all_reduce(keys, op=dist.ReduceOp.MIN)
+    return keys
+
+
+def corpus_ranks(shard: CorpusShard, Q, own_global, labels, ops=None, k=0, world=1, workspace=None):
+    """The fused pass.  Returns (ranks [R, Nq] int64 = 0-based position of the best GT-positive moment in the
+    global (score, id) order -- ``evaluate.py:77``'s MR --, top-k (dist, idx) or (None, None)).
+
+    Raises IndexError when some query has no ground-truth-positive moment, like ``np.where(...)[0][0]`` does
+    in the reference (Q3)."""
+    ops = ops or HipOps()
+    keys = best_positive_keys(shard, Q, own_global, labels, ops, world)
+    if bool((keys == KEY_INF).any()):
+        raise IndexError("index 0 is out of bounds for axis 0 with size 0 (no ground-truth-positive moment)")
+    rank_dist, rank_idx = _unpack_key(keys)
+    od, oi, counts = ops.score_topk(Q, shard.bank, k, rank_dist.contiguous(), rank_idx.contiguous(), workspace=workspace)
+    dist = _dist() if world > 1 else None
+    if dist is not None:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        if k > 0:
+            od, oi = gather_merge_topk(od, oi, ops, world)
+    return counts, od, oi
+
+
+def corpus_topk(shard: CorpusShard, Q, k, ops=None, world=1, workspace=None):
+    ops = ops or HipOps()
+    od, oi, _ = ops.score_topk(Q, shard.bank, k, None, None, workspace=workspace)
+    if world > 1 and _dist() is not None:
+        od, oi = gather_merge_topk(od, oi, ops, world)
+    return od, oi
+
+
+def gather_merge_topk(od, oi, ops, world):
+    """The one exchange step of the path: all_gather the per-shard [Nq, k] lists (dist and ids as one packed
+    int64 key tensor -> a single collective), then merge with the (distance, id) tie-break."""
+    dist = _dist()
+    packed = torch.where(oi >= 0, _pack_key(od, oi.clamp(min=0)), torch.full_like(oi, KEY_INF))
+    parts = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(parts, packed)
+    allk = torch.stack(parts)                                             # [G, Nq, k]
+    pd, pi = _unpack_key(allk)
+    pi = torch.where(allk == KEY_INF, torch.full_like(pi, -1), pi)
+    return ops.topk_merge(pd.contiguous(), pi.contiguous())
+
+
+class TorchCpuOps:
+    """The same provider interface on CPU tensors with plain torch ops.
+
+    This is the CPU *device* of the API (``evaluate(..., device='cpu')``, BASELINE config 0, and the
+    multi-rank plumbing tests under gloo) -- it is selected only by an explicit CPU device, never as a
+    substitute when a ROCm device was asked for."""
+
+    @dataclass
+    class Bank:
+        emb: torch.Tensor
+        clip_off: torch.Tensor
+        id_base: int
+
+        @property
+        def counts(self):
+            return (self.clip_off[1:] - self.clip_off[:-1]).tolist()
+
+    def make_bank(self, emb, clip_off, id_base):
+        return TorchCpuOps.Bank(emb.float().cpu(), clip_off.cpu(), int(id_base))
+
+    def encode_clips(self, model, seg, ctx, clip_off):
+        n = (clip_off[1:] - clip_off[:-1]).long()
+        vid = torch.repeat_interleave(torch.arange(len(n)), n)
+        t = torch.arange(int(clip_off[-1])) - clip_off[:-1].long()[vid]
+        nn_ = n[vid].float()
+        x = torch.cat([seg, ctx[vid], (t.float() / nn_)[:, None], ((t + 1).float() / nn_)[:, None]], dim=1)
+        with torch.no_grad():
+            return model(x)
+
+    def encode_queries(self, model, tokens):
+        with torch.no_grad():
+            return model(tokens, False, "cpu")
+
+    @staticmethod
+    def _video_scores(dist_v):                      # dist_v [Nq, n] -> [Nq, M] in generate_moments order
+        n = dist_v.shape[1]
+        cols = []
+        for s, e in generate_moments(n):
+            acc = dist_v[:, s]
+            for c in range(s + 1, e + 1):
+                acc = acc + dist_v[:, c]
+            cols.append(acc / float(e - s + 1))
+        return torch.stack(cols, dim=1) if cols else dist_v.new_zeros((dist_v.shape[0], 0))
+
+    def _dense(self, Q, bank, eps=1e-6):
+        out = []
+        off = bank.clip_off.tolist()
+        for v in range(len(off) - 1):
+            V = bank.emb[off[v]:off[v + 1]]
+            d = ((V[None, :, :] - Q[:, None, :]) + eps).pow(2).sum(-1).sqrt()
+            out.append(self._video_scores(d))
+        return torch.cat(out, dim=1) if out else Q.new_zeros((Q.shape[0], 0))
+
+    def score_own(self, Q, bank, own_local, eps=1e-6):
+        counts = bank.counts
+        nmax = max(counts) if counts else 0
+        out = torch.full((Q.shape[0], nmax * (nmax + 1) // 2), float("inf"))
+        off = bank.clip_off.tolist()
+        for q, v in enumerate(own_local.tolist()):
+            V = bank.emb[off[v]:off[v + 1]]
+            d = ((V - Q[q][None, :]) + eps).pow(2).sum(-1).sqrt()[None, :]
+            sc = self._video_scores(d)[0]
+            out[q, :sc.numel()] = sc
+        return out
+
+    def score_topk(self, Q, bank, k, rank_dist, rank_idx, workspace=None):
+        sc = self._dense(Q, bank)
+        ids = bank.id_base + torch.arange(sc.shape[1])
+        keys = _pack_key(sc, ids[None, :].expand_as(sc))
+        counts = None
+        if rank_dist is not None:
+            kstar = _pack_key(rank_dist.reshape(-1, Q.shape[0]), rank_idx.reshape(-1, Q.shape[0]))
+            counts = (keys[None, :, :] < kstar[:, :, None]).sum(-1)
+        od = oi = None
+        if k > 0:
+            srt = keys.sort(dim=1).values[:, :k]
+            pad = k - srt.shape[1]
+            if pad > 0:
+                srt = torch.cat([srt, torch.full((srt.shape[0], pad), KEY_INF, dtype=torch.int64)], dim=1)
+            od, oi = _unpack_key(srt)
+            od = torch.where(srt == KEY_INF, torch.full_like(od, float("inf")), od)
+            oi = torch.where(srt == KEY_INF, torch.full_like(oi, -1), oi)
+        return od, oi, counts
+
+    def topk_merge(self, part_dist, part_idx):
+        G, Nq, k = part_dist.shape
+        keys = torch.where(part_idx >= 0, _pack_key(part_dist, part_idx.clamp(min=0)), torch.full_like(part_idx, KEY_INF))
+        srt = keys.permute(1, 0, 2).reshape(Nq, G * k).sort(dim=1).values[:, :k]
+        od, oi = _unpack_key(srt)
+        od = torch.where(srt == KEY_INF, torch.full_like(od, float("inf")), od)
+        oi = torch.where(srt == KEY_INF, torch.full_like(oi, -1), oi)
+        return od, oi
+
+
+def ops_for(device):
+    """Provider by DEVICE: a ROCm device gets the HIP kernels (and raises if they are unavailable)."""
+    return HipOps() if torch.device(device).type == "cuda" else TorchCpuOps()

@@ -1,0 +1,109 @@
+"""Corpus-wide moment retrieval with the reference's ``evaluate`` surface (``model/evaluate.py:19-90``).
+
+``evaluate(model, video_iterator, lang_iterator, annotations, device, ...)`` consumes the same iterators and
+returns the same dict (``{"model, IoU=0.5": {"R@1", "R@10", "R@100", "MR"}, ...}``), but batches internally:
+all clips are embedded in one clip-encoder launch sequence, all queries in one BiLSTM pass, and every
+query is ranked against every moment of every video by the fused scoring kernel -- the Nq x Nv x M Python
+iterations and per-moment ``.item()`` syncs of ``evaluate.py:49-65`` do not exist here.  What the metrics
+need is the 0-based rank of the best ground-truth-positive moment (``:77``), which the kernel counts
+directly; ``R@k`` is ``rank < k`` (``:80``).
+
+Differences kept on purpose: ties are broken by global moment id (the reference's
+unstable argsort leaves them unspecified); ``np.random.choice`` is drawn only when 'chance' is requested
+(Q7).  A query without any positive moment raises IndexError as in the reference (Q3).
+"""
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+import torch
+
+from . import engine
+
+
+def get_metrics(recalls):
+    """lists -> ``{"R@k": mean*100, "MR": median}``."""
+    return {(name if name == "MR" else f"R@{name}"): (np.median(v) if name == "MR" else np.mean(v) * 100)
+            for name, v in recalls.items()}
+
+
+def _drain_videos(video_iterator):
+    names, feats = [], []
+    for batch in video_iterator:
+        names.append(batch["video"])
+        feats.append(batch["feature"])
+    return names, feats
+
+
+def _drain_queries(lang_iterator):
+    tokens, videos, annot_ids = [], [], []
+    for batch in lang_iterator:
+        tokens.append(batch["feature"])
+        videos.append(batch["video"])
+        annot_ids.append(batch["annot_id"])
+    return tokens, videos, annot_ids
+
+
+def embed_corpus(model, video_iterator, device, ops, rank=0, world=1):
+    """-> (CorpusShard, video names).  Uses the dataset's packed FeatureBank (factored clip encoder, one
+    launch sequence for the whole shard) when the iterator exposes one; otherwise embeds the per-video
+    ``[n, 2F+2]`` tensors the iterator yields, concatenated into one batch."""
+    names, feats = _drain_videos(video_iterator)
+    dataset = getattr(video_iterator, "dataset", None)
+    if hasattr(dataset, "feature_bank"):
+        return engine.build_corpus(model, dataset.feature_bank(names), device, ops, rank, world), names
+    counts = [int(f.shape[0]) for f in feats]
+    with torch.no_grad():
+        emb = model(torch.cat(feats).to(device)) if feats else torch.zeros((0, 1))
+    return engine.corpus_from_embeddings(emb, counts, device, ops, rank, world), names
+
+
+def evaluate(model, video_iterator, lang_iterator, annotations, device, preliminary=100, model_types=['model'],
+             iou_thresholds=[0.5, 0.7], rank=0, world=1, return_topk=0):
+    was_training = model.training
+    model.eval()
+    ops = engine.ops_for(device)
+    shard, names = embed_corpus(model, video_iterator, device, ops, rank, world)
+    video_index = {name: i for i, name in enumerate(names)}
+
+    tokens, q_videos, annot_ids = _drain_queries(lang_iterator)
+    if not tokens:
+        model.train(was_training)
+        return {f"{mt}, IoU={thr}": get_metrics({1: [], 10: [], 100: [], "MR": []})
+                for mt, thr in itertools.product(model_types, iou_thresholds)}
+    with torch.no_grad():
+        Q = engine.encode_queries(model, torch.cat(tokens), device, ops, rank, world)
+    own = np.asarray([video_index[v] for v in q_videos], np.int64)
+    times = [annotations[a]["times"] for a in annot_ids]
+    labels = engine.gt_label_table(times, shard.counts_all[own], list(iou_thresholds), strict=True)
+    ranks, top_dist, top_idx = engine.corpus_ranks(shard, Q, own, labels, ops, k=return_topk, world=world)
+    ranks = ranks.cpu().numpy()
+
+    recalls = {}
+    total = int(shard.mom_off_all[-1])
+    for r, thr in enumerate(iou_thresholds):
+        if "model" in model_types:
+            recalls[("model", thr)] = {1: (ranks[r] < 1).astype(int), 10: (ranks[r] < 10).astype(int),
+                                       100: (ranks[r] < 100).astype(int), "MR": ranks[r]}
+        if "chance" in model_types:
+            first = np.empty(len(own), np.int64)
+            for q in range(len(own)):                      # same draw as evaluate.py:68, one per query
+                perm = np.random.choice(np.arange(total), size=total, replace=False)
+                base = int(shard.mom_off_all[own[q]])
+                pos = np.nonzero(labels[r, q])[0] + base
+                first[q] = np.nonzero(np.isin(perm, pos))[0][0]
+            recalls[("chance", thr)] = {1: (first < 1).astype(int), 10: (first < 10).astype(int),
+                                        100: (first < 100).astype(int), "MR": first}
+    if preliminary and len(own) > preliminary and rank == 0:
+        for upto in range(preliminary + 1, len(own), preliminary):
+            print()
+            for (mt, thr), rec in recalls.items():
+                part = get_metrics({k: v[:upto] for k, v in rec.items()})
+                print(f"{mt}, IoU={thr}:\t", "".join(f"{n}: {v:.4f}\t" for n, v in part.items()))
+    model.train(was_training)
+    out = {f"{mt}, IoU={thr}": get_metrics(recalls[(mt, thr)])
+           for mt, thr in itertools.product(model_types, iou_thresholds) if (mt, thr) in recalls}
+    if return_topk:
+        return out, (top_dist, top_idx)
+    return out
