@@ -145,6 +145,14 @@ int vfr_math_f32(int op, const float *x, const float *y, float *out, int64_t n, 
  * Both produce identical bits; the switch exists so tests can prove that on the device.         */
 int vfr_set_option(const char *name, int value);
 int vfr_get_option(const char *name);
+/* vfr_set_option("profile", 1): every instrumented launch is bracketed by two hipEvents recorded on
+ * the launch stream.  After the caller has synchronised the device, vfr_profile_read(site, ...) folds
+ * the finished pairs and returns the site's accumulated device time and launch count (reset != 0
+ * clears all sites afterwards).  Sites are 1 .. vfr_profile_sites()-1, named by
+ * vfr_profile_site_name().  This is how bench.py measures the dominant kernel's launch duration.   */
+int vfr_profile_sites(void);
+const char *vfr_profile_site_name(int site);
+int vfr_profile_read(int site, double *total_ms, int64_t *launches, int reset);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

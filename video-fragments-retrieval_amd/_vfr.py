@@ -26,6 +26,9 @@ SIGNATURES = {
     "vfr_last_error": (ctypes.c_char_p, []),
     "vfr_set_option": (_i32, [ctypes.c_char_p, _i32]),
     "vfr_get_option": (_i32, [ctypes.c_char_p]),
+    "vfr_profile_sites": (_i32, []),
+    "vfr_profile_site_name": (ctypes.c_char_p, [_i32]),
+    "vfr_profile_read": (_i32, [_i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), _i32]),
     "vfr_math_f32": (_i32, [_i32, _vp, _vp, _vp, _i64, _vp]),
     "vfr_segment_pool_norm_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "vfr_segment_pool_norm_batch_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -99,6 +102,21 @@ def set_option(name: str, value: int) -> None:
 
 def get_option(name: str) -> int:
     return int(lib().vfr_get_option(name.encode()))
+
+
+def profile_read(reset: bool = True) -> dict:
+    """{site name: (total device ms, launches)} since the last reset.  Synchronise the device first."""
+    l = lib()
+    out = {}
+    n = l.vfr_profile_sites()
+    for site in range(1, n):
+        ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        _check(l.vfr_profile_read(site, ctypes.byref(ms), ctypes.byref(cnt), 0), "vfr_profile_read")
+        if cnt.value:
+            out[l.vfr_profile_site_name(site).decode()] = (ms.value, cnt.value)
+    if reset:
+        _check(l.vfr_profile_read(1, None, None, 1), "vfr_profile_read")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -200,15 +218,18 @@ class VideoBank:
     ``max_clips`` / ``total_moments`` are host ints computed once at construction (one D2H of two scalars).
     """
 
-    def __init__(self, emb: torch.Tensor, clip_off: torch.Tensor, id_base: int = 0):
+    def __init__(self, emb: torch.Tensor, clip_off: torch.Tensor, id_base: int = 0, max_clips: int | None = None,
+                 total_moments: int | None = None):
         self.emb = _dev(emb, torch.float32, "emb")
         self.clip_off = _dev(clip_off, torch.int32, "clip_off")
         self.mom_off = moment_offsets(self.clip_off)
-        n = self.clip_off[1:] - self.clip_off[:-1]
         self.num_videos = int(self.clip_off.numel() - 1)
-        self.max_clips = int(n.max()) if self.num_videos else 0
+        if max_clips is None or total_moments is None:          # two scalar D2H reads, skipped when the host knows
+            n = self.clip_off[1:] - self.clip_off[:-1]
+            max_clips = int(n.max()) if self.num_videos else 0
+            total_moments = int(self.mom_off[-1])
+        self.max_clips, self.total_moments = int(max_clips), int(total_moments)
         self.total_clips = int(self.emb.shape[0])
-        self.total_moments = int(self.mom_off[-1])
         self.id_base = int(id_base)
         self.dim = int(self.emb.shape[1])
 

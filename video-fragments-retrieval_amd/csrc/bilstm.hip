@@ -103,13 +103,16 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
     const float *bih[2] = {bih_f, bih_b}, *bhh[2] = {bhh_f, bhh_b};
     const int G = 4 * H;
 
+    {
+    vfr::ProfScope prof(vfr::SITE_EMBED, st);
     hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(B * T, 256)), dim3(256), 0, st, tokens, B * T, vocab,
                        emb, len_tab, E, w.X);
+    }
     VFR_CHECK_LAUNCH("embed_kernel");
     for (int d = 0; d < 2; ++d) {
         vfr::GemmArgs g{};
         g.A = w.X; g.lda = E; g.W = Wih[d]; g.ldw = E; g.out = w.gin[d]; g.ldo = G; g.M = B * T; g.N = G; g.K = E;
-        g.bias = bih[d]; g.bias2 = bhh[d]; g.epi = vfr::EPI_BIAS2;
+        g.bias = bih[d]; g.bias2 = bhh[d]; g.epi = vfr::EPI_BIAS2; g.site = vfr::SITE_GEMM_LSTM_IN;
         if (int rc = vfr::gemm_nt(g, st)) return rc;
     }
     if (hipMemsetAsync(w.c, 0, (size_t)2 * B * H * sizeof(float), st) != hipSuccess ||
@@ -122,15 +125,19 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
             g.A = w.hcat + (size_t)d * H; g.lda = 2 * H; g.W = Whh[d]; g.ldw = H;
             g.Cin = w.gin[d] + (size_t)t * G; g.ldc = (int64_t)T * G;
             g.out = w.gates + (size_t)d * B * G; g.ldo = G; g.M = B; g.N = G; g.K = H;
+            g.site = vfr::SITE_GEMM_LSTM_REC;
             if (int rc = vfr::gemm_nt(g, st)) return rc;
         }
+        {
+        vfr::ProfScope prof(vfr::SITE_LSTM_POINTWISE, st);
         hipLaunchKernelGGL(vfr::lstm_pointwise_kernel, dim3((unsigned)vfr::cdiv(2 * B * H, 256)), dim3(256), 0, st,
                            w.gates, w.c, w.hcat, B, H);
+        }
         VFR_CHECK_LAUNCH("lstm_pointwise_kernel");
     }
     vfr::GemmArgs g{};
     g.A = w.hcat; g.lda = 2 * H; g.W = Wfc; g.ldw = 2 * H; g.out = out; g.ldo = D; g.M = B; g.N = D; g.K = 2 * H;
-    g.bias = bfc; g.epi = vfr::EPI_BIAS;
+    g.bias = bfc; g.epi = vfr::EPI_BIAS; g.site = vfr::SITE_GEMM_LANG_FC;
     return vfr::gemm_nt(g, st);
 }
 

@@ -72,15 +72,150 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// MFMA chain kernel: 128x128 block tile, BK = 32, 4 waves as 2(M) x 2(N), each wave 2x2 tiles of
+// v_mfma_f32_32x32x2_f32 (64 accumulator VGPRs).  One MFMA consumes k, k+1 in order
+// (D = fma(a_k1, b_k1, fma(a_k0, b_k0, C))), and the k-loop below walks k strictly ascending, so every
+// output element is the same fp32 chain the VALU kernel and the oracle compute -- identical bits.
+//
+// Operand fetch: LDS tiles are row-major [row][k] with a 36-float row stride (conflict-free for
+// ds_read_b128: 36r mod 64 hits 16 distinct 4-bank slots for any 16 rows distinct mod 16).  A lane reads
+// float4 = k..k+3 of its row; lane half h = lane>>5 uses (.x,.z) or (.y,.w) -- the MFMA wants
+// A[i = lane&31][k = h] -- so one 16-byte read feeds two MFMA k-steps.  Global->register prefetch of the
+// next K-tile is issued before the 64 MFMAs of the current tile and written to LDS after them.
+// fp32 MFMA runs at the fp32 vector rate (64 cycles per 32x32x2 per SIMD): this kernel is MFMA-pipe-bound,
+// staging has ~4096 cycles of cover per K-tile.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MBM = 128, MBN = 128, MBK = 32, MLD = 36;
+
+template <bool VEC>
+__device__ __forceinline__ float4 load4_guard(const float *__restrict__ P, int64_t ld, int64_t row, int64_t nrows,
+                                              int k, int K)
+{
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row >= nrows) return r;
+    const float *p = P + row * ld + k;
+    if (VEC && k + 3 < K) return *reinterpret_cast<const float4 *>(p);
+    if (k < K) r.x = p[0];
+    if (k + 1 < K) r.y = p[1];
+    if (k + 2 < K) r.z = p[2];
+    if (k + 3 < K) r.w = p[3];
+    return r;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_nt_mfma(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) float As[MBM * MLD];
+    __shared__ __attribute__((aligned(16))) float Ws[MBN * MLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * MBM;
+    const int n0 = blockIdx.y * MBN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = n0 + wn * 64 + ni * 32 + l31;
+                acc[mi][ni][r] = (g.Cin && row < g.M && col < g.N) ? g.Cin[row * g.ldc + col] : 0.0f;
+            }
+
+    float4 ra[4], rw[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
+            ra[i] = load4_guard<VEC>(g.A, g.lda, m0 + row, g.M, k0 + kk, g.K);
+            rw[i] = load4_guard<VEC>(g.W, g.ldw, (int64_t)n0 + row, g.N, k0 + kk, g.K);
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
+            *reinterpret_cast<float4 *>(&As[row * MLD + kk]) = ra[i];
+            *reinterpret_cast<float4 *>(&Ws[row * MLD + kk]) = rw[i];
+        }
+    };
+
+    const int nk = (g.K + MBK - 1) / MBK;
+    if (nk > 0) { gload(0); swrite(); }
+    __syncthreads();
+    const float *ap = &As[(wm * 64 + l31) * MLD];
+    const float *wp = &Ws[(wn * 64 + l31) * MLD];
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload((kt + 1) * MBK);
+#pragma unroll
+        for (int k4 = 0; k4 < MBK / 4; ++k4) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(ap + k4 * 4);
+            const float4 a1 = *reinterpret_cast<const float4 *>(ap + 32 * MLD + k4 * 4);
+            const float4 b0 = *reinterpret_cast<const float4 *>(wp + k4 * 4);
+            const float4 b1 = *reinterpret_cast<const float4 *>(wp + 32 * MLD + k4 * 4);
+            {   // k = 4*k4 + h
+                const float fa0 = h ? a0.y : a0.x, fa1 = h ? a1.y : a1.x, fb0 = h ? b0.y : b0.x, fb1 = h ? b1.y : b1.x;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc[1][1], 0, 0, 0);
+            }
+            {   // k = 4*k4 + 2 + h
+                const float fa0 = h ? a0.w : a0.z, fa1 = h ? a1.w : a1.z, fb0 = h ? b0.w : b0.z, fb1 = h ? b1.w : b1.z;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) { swrite(); __syncthreads(); }
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + l31;
+            if (col >= g.N) continue;
+            float badd = 0.0f;
+            if (g.epi & EPI_BIAS2) badd = g.bias[col] + g.bias2[col];
+            else if (g.epi & EPI_BIAS) badd = g.bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= g.M) continue;
+                float v = acc[mi][ni][r];
+                if (g.epi & (EPI_BIAS | EPI_BIAS2)) v = v + badd;
+                if (g.epi & EPI_RELU) v = v > 0.0f ? v : 0.0f;
+                g.out[row * g.ldo + col] = v;
+            }
+        }
+}
+
 int gemm_nt(const GemmArgs &g, hipStream_t st)
 {
     if (g.M == 0 || g.N == 0) return VFR_OK;
     VFR_REQUIRE(g.A && g.W && g.out && g.M > 0 && g.N > 0 && g.K >= 0, VFR_EINVAL, "gemm_nt: bad argument");
     VFR_REQUIRE(!(g.epi & (EPI_BIAS | EPI_BIAS2)) || g.bias, VFR_EINVAL, "gemm_nt: bias flag without bias");
     VFR_REQUIRE(!(g.epi & EPI_BIAS2) || g.bias2, VFR_EINVAL, "gemm_nt: bias2 flag without bias2");
-    dim3 grid((unsigned)cdiv(g.M, VBM), (unsigned)cdiv(g.N, VBN));
-    hipLaunchKernelGGL(gemm_nt_valu, grid, dim3(256), 0, st, g);
-    VFR_CHECK_LAUNCH("gemm_nt_valu");
+    ProfScope prof(g.site, st);
+    if (opt_gemm() == 0) {
+        dim3 grid((unsigned)cdiv(g.M, VBM), (unsigned)cdiv(g.N, VBN));
+        hipLaunchKernelGGL(gemm_nt_valu, grid, dim3(256), 0, st, g);
+        VFR_CHECK_LAUNCH("gemm_nt_valu");
+        return VFR_OK;
+    }
+    const bool vec = ((g.lda | g.ldw) & 3) == 0 && ((((uintptr_t)g.A) | ((uintptr_t)g.W)) & 15) == 0;
+    dim3 grid((unsigned)cdiv(g.M, MBM), (unsigned)cdiv(g.N, MBN));
+    if (vec) hipLaunchKernelGGL(gemm_nt_mfma<true>, grid, dim3(256), 0, st, g);
+    else     hipLaunchKernelGGL(gemm_nt_mfma<false>, grid, dim3(256), 0, st, g);
+    VFR_CHECK_LAUNCH("gemm_nt_mfma");
     return VFR_OK;
 }
 
@@ -94,5 +229,6 @@ extern "C" int vfr_linear_f32(const float *A, int64_t M, int K, const float *W, 
     g.A = A; g.lda = K; g.W = W; g.ldw = K; g.out = out; g.ldo = N; g.M = M; g.N = N; g.K = K;
     g.bias = b;
     g.epi = (b ? vfr::EPI_BIAS : 0) | (relu ? vfr::EPI_RELU : 0);
+    g.site = vfr::SITE_LINEAR;
     return vfr::gemm_nt(g, vfr::as_stream(stream));
 }

@@ -467,6 +467,7 @@ static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st)
     const int tasks = a.num_groups * a.num_chunks;
     const size_t lds = (size_t)4 * a.ds_rows * 64 * sizeof(float);
     dim3 grid((unsigned)cdiv(tasks, 4)), block(256);
+    ProfScope prof(MODE == 0 ? SITE_SCORE_DENSE : SITE_SCORE_FUSED, st);
 #define VFR_LAUNCH(DT, KPL)                                                                              \
     hipLaunchKernelGGL((score_kernel<DT, MODE, KPL>), grid, block, lds, st, a.Q, a.V, a.clip_off, a.mom_off, \
                        a.rank_dist, a.rank_idx, a)
@@ -558,6 +559,7 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
             return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: hipMemsetAsync failed");
     }
     if (k > 0) {
+        vfr::ProfScope prof(vfr::SITE_TOPK_MERGE, st);
         dim3 grid((unsigned)vfr::cdiv(Nq, 4)), block(256);
         if (kpl == 4)
             hipLaunchKernelGGL((vfr::topk_merge_tasks_kernel<4>), grid, block, 0, st, w.buf, w.cnt, a.num_groups,

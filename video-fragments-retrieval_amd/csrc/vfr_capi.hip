@@ -3,11 +3,45 @@
 #include "vfr_math.cuh"
 
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace vfr {
 
 static thread_local char g_err[512] = "";
 static int g_opt_gemm = 1;
+static int g_opt_profile = 0;
+
+struct ProfPair { int site; hipEvent_t a, b; };
+static std::vector<ProfPair> g_pairs;          // recorded, not yet read
+static std::vector<hipEvent_t> g_free;         // recycled events
+static hipEvent_t g_open[SITE_COUNT];
+static double g_total_ms[SITE_COUNT];
+static long long g_launches[SITE_COUNT];
+static std::mutex g_prof_mu;
+
+bool profiling() { return g_opt_profile != 0; }
+static hipEvent_t take_event()
+{
+    if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void prof_begin(int site, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEvent_t e = take_event();
+    (void)hipEventRecord(e, st);
+    g_open[site] = e;
+}
+void prof_end(int site, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEvent_t e = take_event();
+    (void)hipEventRecord(e, st);
+    g_pairs.push_back({site, g_open[site], e});
+}
 
 char *error_buffer() { return g_err; }
 int fail(int code, const char *fmt, ...)
@@ -47,12 +81,41 @@ const char *vfr_last_error(void) { return vfr::g_err; }
 int vfr_set_option(const char *name, int value)
 {
     if (name && !strcmp(name, "gemm")) { vfr::g_opt_gemm = value; return VFR_OK; }
+    if (name && !strcmp(name, "profile")) { vfr::g_opt_profile = value; return VFR_OK; }
     return vfr::fail(VFR_EINVAL, "vfr_set_option: unknown option '%s'", name ? name : "(null)");
 }
 int vfr_get_option(const char *name)
 {
     if (name && !strcmp(name, "gemm")) return vfr::g_opt_gemm;
+    if (name && !strcmp(name, "profile")) return vfr::g_opt_profile;
     return vfr::fail(VFR_EINVAL, "vfr_get_option: unknown option '%s'", name ? name : "(null)");
+}
+
+int vfr_profile_sites(void) { return vfr::SITE_COUNT; }
+
+const char *vfr_profile_site_name(int site)
+{
+    static const char *names[vfr::SITE_COUNT] = {
+        "none", "gemm_vis_seg", "gemm_vis_ctx", "vis_hidden", "gemm_vis_out", "embed", "gemm_lstm_in", "gemm_lstm_rec",
+        "lstm_pointwise", "gemm_lang_fc", "score_fused", "topk_merge", "score_dense", "score_own", "pool", "linear",
+        "conv3x3", "pool2d", "normalize"};
+    return site >= 0 && site < vfr::SITE_COUNT ? names[site] : "?";
+}
+
+int vfr_profile_read(int site, double *total_ms, int64_t *launches, int reset)
+{
+    VFR_REQUIRE(site >= 0 && site < vfr::SITE_COUNT, VFR_EINVAL, "vfr_profile_read: bad site %d", site);
+    std::lock_guard<std::mutex> lk(vfr::g_prof_mu);
+    for (auto &p : vfr::g_pairs) {            // fold every completed pair (caller synchronised the device)
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { vfr::g_total_ms[p.site] += ms; vfr::g_launches[p.site] += 1; }
+        vfr::g_free.push_back(p.a); vfr::g_free.push_back(p.b);
+    }
+    vfr::g_pairs.clear();
+    if (total_ms) *total_ms = vfr::g_total_ms[site];
+    if (launches) *launches = vfr::g_launches[site];
+    if (reset) for (int i = 0; i < vfr::SITE_COUNT; ++i) { vfr::g_total_ms[i] = 0; vfr::g_launches[i] = 0; }
+    return VFR_OK;
 }
 
 int vfr_math_f32(int op, const float *x, const float *y, float *out, int64_t n, vfr_stream_t stream)

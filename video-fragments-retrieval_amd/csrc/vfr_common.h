@@ -18,6 +18,25 @@ inline hipStream_t as_stream(vfr_stream_t s) { return reinterpret_cast<hipStream
 // option switches (vfr_set_option)
 int opt_gemm();
 
+// ---- launch-site profiler (vfr_set_option("profile", 1)): HIP events recorded on the launch stream
+// around every instrumented launch; vfr_profile_read() turns them into per-site totals after a sync.
+enum Site : int {
+    SITE_NONE = 0,
+    SITE_GEMM_VIS_SEG, SITE_GEMM_VIS_CTX, SITE_VIS_HIDDEN, SITE_GEMM_VIS_OUT,
+    SITE_EMBED, SITE_GEMM_LSTM_IN, SITE_GEMM_LSTM_REC, SITE_LSTM_POINTWISE, SITE_GEMM_LANG_FC,
+    SITE_SCORE_FUSED, SITE_TOPK_MERGE, SITE_SCORE_DENSE, SITE_SCORE_OWN, SITE_POOL, SITE_LINEAR,
+    SITE_CONV, SITE_POOL2D, SITE_NORMALIZE,
+    SITE_COUNT
+};
+bool profiling();
+void prof_begin(int site, hipStream_t st);
+void prof_end(int site, hipStream_t st);
+struct ProfScope {
+    int site; hipStream_t st; bool on;
+    ProfScope(int s, hipStream_t t) : site(s), st(t), on(s != SITE_NONE && profiling()) { if (on) prof_begin(site, st); }
+    ~ProfScope() { if (on) prof_end(site, st); }
+};
+
 #define VFR_REQUIRE(cond, code, ...)                         \
     do {                                                     \
         if (!(cond)) return ::vfr::fail((code), __VA_ARGS__); \
@@ -48,6 +67,7 @@ struct GemmArgs {
     float *out; int64_t ldo;
     int64_t M; int N; int K;
     int epi;
+    int site;                          // profiler site (SITE_NONE = not instrumented)
 };
 int gemm_nt(const GemmArgs &g, hipStream_t st);
 

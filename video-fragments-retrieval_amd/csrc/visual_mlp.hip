@@ -63,15 +63,19 @@ int vfr_visual_mlp_f32(const float *seg, const float *ctx, const int32_t *clip_o
     const int ldw = 2 * F + 2;
     vfr::GemmArgs g{};
     g.A = seg; g.lda = F; g.W = W1; g.ldw = ldw; g.out = S; g.ldo = hid; g.M = total_clips; g.N = hid; g.K = F;
+    g.site = vfr::SITE_GEMM_VIS_SEG;
     if (int rc = vfr::gemm_nt(g, st)) return rc;
-    g.A = ctx; g.W = W1 + F; g.out = Cx; g.M = Nv;
+    g.A = ctx; g.W = W1 + F; g.out = Cx; g.M = Nv; g.site = vfr::SITE_GEMM_VIS_CTX;
     if (int rc = vfr::gemm_nt(g, st)) return rc;
+    {
+    vfr::ProfScope prof(vfr::SITE_VIS_HIDDEN, st);
     hipLaunchKernelGGL(vfr::visual_hidden_kernel, dim3(total_clips), dim3(256), 0, st, S, Cx, clip_offsets, Nv,
                        total_clips, hid, W1, ldw, F, b1);
+    }
     VFR_CHECK_LAUNCH("visual_hidden_kernel");
     vfr::GemmArgs g2{};
     g2.A = S; g2.lda = hid; g2.W = W2; g2.ldw = hid; g2.out = out; g2.ldo = D; g2.M = total_clips; g2.N = D;
-    g2.K = hid; g2.bias = b2; g2.epi = vfr::EPI_BIAS;
+    g2.K = hid; g2.bias = b2; g2.epi = vfr::EPI_BIAS; g2.site = vfr::SITE_GEMM_VIS_OUT;
     return vfr::gemm_nt(g2, st);
 }
 

@@ -154,40 +154,61 @@ def _unpack_key(key: torch.Tensor):
     return bits.view(torch.float32), key & 0xFFFFFFFF
 
 
-def best_positive_keys(shard: CorpusShard, Q, own_global, labels, ops, world=1):
-    """Per (threshold, query): key of the best ground-truth-positive moment = min over positives of
-    (score, global id).  Only the rank that owns the query's video can see it; others contribute KEY_INF."""
-    device = shard.device
+@dataclass
+class QueryGT:
+    """Ground truth of a query batch, resident on the device (built once per batch, outside any timed loop)."""
+    num_thresholds: int
+    num_queries: int
+    sel: object = None           # int64 [n_sel] positions of the queries whose own video lives in this shard
+    own_local: object = None     # int32 [n_sel] shard-local video index
+    labels: object = None        # bool  [R, n_sel, Mloc]
+    base: object = None          # int64 [n_sel] global id of the own video's first moment
+
+
+def prepare_gt(shard: CorpusShard, own_global, labels) -> QueryGT:
     own = np.asarray(own_global, np.int64)
-    local = (own >= shard.lo) & (own < shard.hi)
     R, Nq, Mmax = labels.shape
-    keys = torch.full((R, Nq), KEY_INF, dtype=torch.int64, device=device)
+    gt = QueryGT(R, Nq)
+    local = (own >= shard.lo) & (own < shard.hi)
     if local.any() and Mmax > 0:
         sel = np.nonzero(local)[0]
-        sel_t = torch.from_numpy(sel).to(device)
-        own_local = torch.from_numpy((own[sel] - shard.lo).astype(np.int32)).to(device)
-        sc = ops.score_own(Q[sel_t].contiguous(), shard.bank, own_local)          # [n_sel, Mloc], +inf padded
-        Mloc = sc.shape[1]
-        lab = torch.from_numpy(labels[:, sel, :Mloc]).to(device)                  # [R, n_sel, Mloc]
-        base = torch.from_numpy(shard.mom_off_all[own[sel]]).to(device)           # global id of local moment 0
-        ids = base[:, None] + torch.arange(Mloc, device=device)[None, :]
-        k = _pack_key(sc, ids)                                                    # [n_sel, Mloc]
-        k = torch.where(lab, k[None].expand(R, -1, -1), torch.full_like(k, KEY_INF)[None].expand(R, -1, -1))
-        keys[:, sel_t] = k.min(dim=2).values
+        nloc = shard.counts_all[shard.lo:shard.hi]
+        nmax = int(nloc.max()) if len(nloc) else 0
+        Mloc = min(Mmax, nmax * (nmax + 1) // 2)
+        dev = shard.device
+        gt.sel = torch.from_numpy(sel).to(dev)
+        gt.own_local = torch.from_numpy((own[sel] - shard.lo).astype(np.int32)).to(dev)
+        gt.labels = torch.from_numpy(np.ascontiguousarray(labels[:, sel, :Mloc])).to(dev)
+        gt.base = torch.from_numpy(shard.mom_off_all[own[sel]]).to(dev)
+    return gt
+
+
+def best_positive_keys(shard: CorpusShard, Q, gt: QueryGT, ops, world=1):
+    """Per (threshold, query): key of the best ground-truth-positive moment = min over positives of
+    (score, global id).  Only the rank that owns the query's video can see it; others contribute KEY_INF."""
+    keys = torch.full((gt.num_thresholds, gt.num_queries), KEY_INF, dtype=torch.int64, device=shard.device)
+    if gt.sel is not None:
+        sc = ops.score_own(Q[gt.sel].contiguous(), shard.bank, gt.own_local)      # [n_sel, Mown], +inf padded
+        M = min(sc.shape[1], gt.labels.shape[2])
+        ids = gt.base[:, None] + torch.arange(M, device=shard.device)[None, :]
+        k = _pack_key(sc[:, :M].contiguous(), ids)                                # [n_sel, M]
+        k = torch.where(gt.labels[:, :, :M], k[None], torch.full_like(k, KEY_INF)[None])
+        keys[:, gt.sel] = k.min(dim=2).values
     dist = _dist() if world > 1 else None
     if dist is not None:
         dist.all_reduce(keys, op=dist.ReduceOp.MIN)
     return keys
 
 
-def corpus_ranks(shard: CorpusShard, Q, own_global, labels, ops=None, k=0, world=1, workspace=None):
+def corpus_ranks(shard: CorpusShard, Q, own_global, labels, ops=None, k=0, world=1, workspace=None, gt=None):
     """The fused pass.  Returns (ranks [R, Nq] int64 = 0-based position of the best GT-positive moment in the
     global (score, id) order -- ``evaluate.py:77``'s MR --, top-k (dist, idx) or (None, None)).
 
     Raises IndexError when some query has no ground-truth-positive moment, like ``np.where(...)[0][0]`` does
     in the reference (Q3)."""
     ops = ops or HipOps()
-    keys = best_positive_keys(shard, Q, own_global, labels, ops, world)
+    gt = gt if gt is not None else prepare_gt(shard, own_global, labels)
+    keys = best_positive_keys(shard, Q, gt, ops, world)
     if bool((keys == KEY_INF).any()):
         raise IndexError("index 0 is out of bounds for axis 0 with size 0 (no ground-truth-positive moment)")
     rank_dist, rank_idx = _unpack_key(keys)
