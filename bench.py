@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--feat-dim", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="256x4000", help="queries x videos for the CPU baseline sample")
+    ap.add_argument("--cpu-sample", default="1024x4000", help="queries x videos for the CPU baseline sample")
     return ap.parse_args()
 
 
