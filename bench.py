@@ -140,7 +140,7 @@ def main():
 
     def make_shard(emb):
         bank = _vfr.VideoBank(emb, clip_off, int(mom_all[lo]), max_clips=int(counts_all[lo:hi].max()),
-                              total_moments=int(mom_all[hi] - mom_all[lo]))
+                              total_moments=int(mom_all[hi] - mom_all[lo]), min_clips=int(counts_all[lo:hi].min()))
         return engine.CorpusShard(bank, lo, hi, counts_all, mom_all, dev)
 
     with torch.no_grad():

@@ -40,7 +40,7 @@ SIGNATURES = {
     "vfr_score_moments_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _vp, _vp]),
     "vfr_score_own_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp]),
     "vfr_score_topk_workspace_bytes": (_sz, [_i64, _i32, _i32]),
-    "vfr_score_topk_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i64, _i32, _vp, _vp, _i32,
+    "vfr_score_topk_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i64, _i32, _vp, _vp, _i32,
                                   _vp, _vp, _vp, _vp, _sz, _vp]),
     "vfr_topk_merge_f32": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "vfr_frames_normalize_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
@@ -219,16 +219,17 @@ class VideoBank:
     """
 
     def __init__(self, emb: torch.Tensor, clip_off: torch.Tensor, id_base: int = 0, max_clips: int | None = None,
-                 total_moments: int | None = None):
+                 total_moments: int | None = None, min_clips: int | None = None):
         self.emb = _dev(emb, torch.float32, "emb")
         self.clip_off = _dev(clip_off, torch.int32, "clip_off")
         self.mom_off = moment_offsets(self.clip_off)
         self.num_videos = int(self.clip_off.numel() - 1)
-        if max_clips is None or total_moments is None:          # two scalar D2H reads, skipped when the host knows
+        if max_clips is None or total_moments is None or min_clips is None:   # scalar D2H reads, skipped when the host knows
             n = self.clip_off[1:] - self.clip_off[:-1]
             max_clips = int(n.max()) if self.num_videos else 0
+            min_clips = int(n.min()) if self.num_videos else 0
             total_moments = int(self.mom_off[-1])
-        self.max_clips, self.total_moments = int(max_clips), int(total_moments)
+        self.max_clips, self.min_clips, self.total_moments = int(max_clips), int(min_clips), int(total_moments)
         self.total_clips = int(self.emb.shape[0])
         self.id_base = int(id_base)
         self.dim = int(self.emb.shape[1])
@@ -276,8 +277,8 @@ def score_topk(Q: torch.Tensor, bank: VideoBank, k: int, rank_dist=None, rank_id
     if workspace is None or workspace.numel() < nbytes:
         workspace = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=Q.device)
     _check(lib().vfr_score_topk_f32(Q.data_ptr(), Nq, bank.emb.data_ptr(), bank.clip_off.data_ptr(),
-                                    bank.mom_off.data_ptr(), bank.num_videos, bank.total_clips, bank.max_clips,
-                                    bank.dim, eps, bank.id_base, k, _ptr(od), _ptr(oi), R, _ptr(rank_dist),
+                                    bank.mom_off.data_ptr(), bank.num_videos, bank.total_clips, bank.min_clips,
+                                    bank.max_clips, bank.dim, eps, bank.id_base, k, _ptr(od), _ptr(oi), R, _ptr(rank_dist),
                                     _ptr(rank_idx), _ptr(count_lt), workspace.data_ptr(), nbytes, _stream()),
            "vfr_score_topk_f32")
     return od, oi, count_lt

@@ -140,7 +140,7 @@ __device__ __forceinline__ unsigned long long key_at(const unsigned long long (&
 // compact the candidate buffer of lane L (wave-uniform): keep the k smallest keys, sorted.
 // returns the new count; *thr_out = k-th smallest key when at least k keys exist.
 template <int KPL>
-__device__ __forceinline__ int compact_buffer(unsigned long long *base, int cnt, int k, int lane,
+__device__ __attribute__((noinline)) int compact_buffer(unsigned long long *base, int cnt, int k, int lane,
                                               unsigned long long *thr_out)
 {
     unsigned long long key[KPL];
@@ -176,6 +176,10 @@ struct ScoreArgs {
     unsigned long long *thr_global;                   // [Nq]
     int num_groups, num_chunks;
     int ds_rows;                                      // LDS rows per wave = max clips per video
+    int total_clips;                                  // rows of V (fast kernel: bound for the staged reads)
+    int min_clips;                                    // smallest clip count in the bank (0 = unknown)
+    int v_lo, v_hi;                                   // video range scored by this launch (chunks partition it)
+    int force_generic;                                // 1: use score_kernel (cooperative compaction) even if fast applies
 };
 
 // MODE 0: dense scores; MODE 1: fused top-k and/or rank counting
@@ -205,8 +209,8 @@ __global__ __launch_bounds__(256) void score_kernel(const float *__restrict__ Qp
         for (int kk = 0; kk < DT; ++kk) qreg[kk] = qrow[kk];
     }
 
-    const int v0 = (int)((int64_t)a.Nv * chunk / a.num_chunks);
-    const int v1 = (int)((int64_t)a.Nv * (chunk + 1) / a.num_chunks);
+    const int v0 = a.v_lo + (int)((int64_t)(a.v_hi - a.v_lo) * chunk / a.num_chunks);
+    const int v1 = a.v_lo + (int)((int64_t)(a.v_hi - a.v_lo) * (chunk + 1) / a.num_chunks);
 
     // selection state (MODE 1)
     unsigned long long thr = KEY_MAX, kstar[MAX_RANK] = {0, 0, 0, 0};
@@ -300,11 +304,345 @@ __global__ __launch_bounds__(256) void score_kernel(const float *__restrict__ Qp
     }
 }
 
+
+// ================================================================================================
+// Fast fused kernel (D = 100, every video has at most NT clips; NT in {6, 21}; NR = rank keys per query).
+//
+// thread = query: a wave owns 64 queries, each lane keeps its query embedding in 50 float2 VGPR pairs.
+//   * V delivery: the clip rows being scored are the same for all 64 lanes.  Each wave stages the next NC
+//     rows (NC * 400 contiguous bytes of V) into a private LDS buffer with coalesced 16-byte vector loads
+//     (issued one group ahead, held in registers while the current group is computed) and reads them back as
+//     broadcast ds_read_b128 -- all lanes the same address, so no bank conflicts and no barrier: a wave never
+//     synchronises with another wave.  (Streaming V through the scalar cache was measured first: s_load returns
+//     out of order, so every 64-byte batch pays a full lgkmcnt(0) round trip -- 10x off the VALU rate.)
+//   * (v - q), (+ eps) are v_pk_add_f32 on float2 pairs; the square-accumulate is a sequential v_fma chain per
+//     clip (canonical order), NC independent chains in flight.
+//   * moment triangle L-outer on the wave's LDS distance column: sums[s] += d[s+L-1] is exactly the canonical
+//     left-to-right sum of d[s..s+L-1]; both loops are fully unrolled so sums[] and the threshold tables are
+//     statically indexed registers.
+//   * thresholds live in SUM space, so the common path has NO division and builds NO key.  For a bound x and
+//     span length L:  hi(x,L) = max{S : fl(S/L) <= x},  lo(x,L) = max{S : fl(S/L) < x}  (fl(S/L) is monotone
+//     in S; found by walking a few ulps around fl(x*L)).  Then
+//         score <  x  <=>  sum <= lo        (rank count, exact)
+//         score == x  <=>  lo < sum <= hi   (a tie: resolved by moment id on the exact path)
+//         score <= thr => sum <= hi(thr)    (top-k candidate, conservative superset)
+//   * only when some lane of the wave has a candidate or a tie is the video re-walked exactly (IEEE division,
+//     64-bit keys, buffer appends) -- rare once the shared threshold has tightened.
+// ================================================================================================
+typedef float float2v __attribute__((ext_vector_type(2)));
+constexpr int FAST_D = 100;
+
+__device__ __forceinline__ float next_up(float x) { return __uint_as_float(__float_as_uint(x) + 1u); }
+__device__ __forceinline__ float next_down(float x) { return __uint_as_float(__float_as_uint(x) - 1u); }
+
+// largest S >= 0 with fl(S/L) < x (STRICT) or <= x;  -1 when there is none;  +inf when x is +inf / NaN
+template <bool STRICT>
+__device__ __attribute__((noinline)) float sum_bound(float x, int L)
+{
+    const float inf = __builtin_inff();
+    if (!(x < inf)) return inf;
+    const float Lf = (float)L;
+    float S = x * Lf;
+    if (!(S < inf)) S = 3.4028234663852886e38f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float u = next_up(S), y = u / Lf;
+        const bool ok = (STRICT ? (y < x) : (y <= x)) && (u < inf);
+        S = ok ? u : S;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float y = S / Lf;
+        const bool ok = STRICT ? (y < x) : (y <= x);
+        S = ok ? S : (S > 0.0f ? next_down(S) : -1.0f);
+    }
+    const float y = S / Lf;
+    return (STRICT ? (y < x) : (y <= x)) ? S : -1.0f;
+}
+
+
+// Lane-parallel tightening of all 64 candidate columns of a task (layout col[slot * 64 + lane]).
+// Every lane bisects on the fp32 bit pattern of the distance for a bound t with count(dist <= t) >= k over ITS
+// column (any such t is a valid filter: at least k moments are that good, so nothing above t can be in the
+// final top-k), drops the entries above t in place and publishes (t, id = max) as its threshold.  No sorting and
+// no cross-lane traffic; all loads are coalesced across the wave.  The merge kernel does the exact ordering.
+__device__ __attribute__((noinline)) void lane_tighten(unsigned long long *col, int lane, int k, int *cnt_io,
+                                                       unsigned long long *thr_io)
+{
+    const int cnt = *cnt_io;
+    int cmax = cnt;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(cmax, off, 64); cmax = o > cmax ? o : cmax; }
+    if (cmax <= k) return;
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;                       // min / max distance bits of this lane's column
+    for (int i = 0; i < cmax; ++i) {
+        if (i < cnt) {
+            const unsigned d = (unsigned)(col[(size_t)i * 64 + lane] >> 32);
+            lo = d < lo ? d : lo;
+            hi = d > hi ? d : hi;
+        }
+    }
+    const bool mine = cnt > k;                                // lanes at or below k keep everything
+    // invariant: count(<= hi) >= k.  count(<= lo-1) = 0 < k.
+    for (int it = 0; it < 16; ++it) {
+        if (__ballot(mine && lo < hi) == 0) break;
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+        for (int i = 0; i < cmax; ++i)
+            if (i < cnt) c += ((unsigned)(col[(size_t)i * 64 + lane] >> 32) <= mid) ? 1 : 0;
+        if (mine && lo < hi) { if (c >= k) hi = mid; else lo = mid + 1; }
+    }
+    if (mine) {
+        int w = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const unsigned long long key = col[(size_t)i * 64 + lane];
+            if ((unsigned)(key >> 32) <= hi) { col[(size_t)w * 64 + lane] = key; ++w; }
+        }
+        *cnt_io = w;
+        const unsigned long long t = ((unsigned long long)hi << 32) | 0xFFFFFFFFull;
+        if (t < *thr_io) *thr_io = t;
+    }
+}
+
+template <int NT> struct FastCfg { static constexpr int NC = 4; };
+template <> struct FastCfg<6> { static constexpr int NC = 3; };
+
+// Thresholds are kept as EXCLUSIVE upper bounds on the fp32 bit pattern of the (non-negative) sum:
+//   score <  x  <=>  bits(sum) < LOX,   score <= x  <=>  bits(sum) < HIX = LOX + delta   (delta in 0..3)
+// "no such sum" is simply 0, +inf needs no special case, and hi costs 2 bits instead of a register.
+__device__ __forceinline__ unsigned excl_bound(float s) { return s < 0.0f ? 0u : __float_as_uint(s) + 1u; }
+
+template <int NT, int KPL, int NR, bool TOPK, bool EXACT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
+void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ Vp, const int32_t *__restrict__ clip_off,
+                       const int64_t *__restrict__ mom_off, const float *__restrict__ rank_dist,
+                       const int64_t *__restrict__ rank_idx, ScoreArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CAP = KPL * 64, NC = FastCfg<NT>::NC, ROW4 = FAST_D / 4, G4 = NC * ROW4;   // float4 per group
+    constexpr int NLD = (G4 + 63) / 64;                                                       // loads per lane
+    constexpr int NRR = NR > 0 ? NR : 1;
+    const int lane = threadIdx.x;
+    const int task = blockIdx.x;
+    const int chunk = task / a.num_groups, group = task - chunk * a.num_groups;
+    float *stage = smem;                              // [2][NC*100]  staged clip rows (double buffer)
+    float *ds = smem + 2 * NC * FAST_D;               // [ceil(NT/NC)*NC][64] clip distances of the current video
+
+    const int64_t qi = (int64_t)group * 64 + lane;
+    const bool active = qi < a.Nq;
+    const float *__restrict__ qrow = Qp + (active ? qi : a.Nq - 1) * FAST_D;
+    float2v qp[FAST_D / 2];
+#pragma unroll
+    for (int j = 0; j < FAST_D / 2; ++j) qp[j] = reinterpret_cast<const float2v *>(qrow)[j];
+
+    const int v0 = a.v_lo + (int)((int64_t)(a.v_hi - a.v_lo) * chunk / a.num_chunks);
+    const int v1 = a.v_lo + (int)((int64_t)(a.v_hi - a.v_lo) * (chunk + 1) / a.num_chunks);
+    const int64_t v4_end = (int64_t)a.total_clips * ROW4;     // float4 count of V: never read past it
+
+    unsigned long long thr = KEY_MAX;
+    int cnt = 0, nlt[NRR] = {0};
+    unsigned long long *col = TOPK ? a.buf + (size_t)task * 64 * CAP : nullptr;   // [slot][lane] candidate columns
+
+    // threshold tables, statically indexed (registers): index L-1
+    unsigned hix_t[TOPK ? NT : 1];                    // top-k filter: bits(sum) < hix_t  <=  score <= thr distance
+    unsigned lox[NRR][NT];                            // rank r: score <  key distance
+    unsigned long long dl[NRR];                       // rank r: 2-bit (HIX - LOX) per L, packed
+    bool wide = false;                                // some delta did not fit 2 bits: treat every video as a tie
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const float x = active ? rank_dist[r * a.Nq + qi] : 0.0f;
+        dl[r] = 0;
+#pragma unroll
+        for (int L = 1; L <= NT; ++L) {
+            const unsigned lo = active ? excl_bound(sum_bound<true>(x, L)) : 0u;
+            const unsigned hi = active ? excl_bound(sum_bound<false>(x, L)) : 0u;
+            const unsigned d = hi - lo;
+            wide = wide || d > 3u;
+            lox[r][L - 1] = lo;
+            dl[r] |= (unsigned long long)(d & 3u) << (2 * (L - 1));
+        }
+    }
+    if (TOPK) {
+#pragma unroll
+        for (int L = 1; L <= NT; ++L) hix_t[L - 1] = active ? 0xFFFFFFFFu : 0u;       // thr = +inf: everything passes
+    }
+    bool dirty = false;
+
+    float4 pre[NLD];                                  // next group's rows, in flight while this group is computed
+    auto gload = [&](int64_t row) {                   // rows [row, row+NC) of V -> registers (coalesced 16 B/lane)
+#pragma unroll
+        for (int t = 0; t < NLD; ++t) {
+            const int idx = lane + 64 * t;
+            const int64_t g4 = row * ROW4 + idx;
+            pre[t] = (idx < G4 && g4 < v4_end) ? reinterpret_cast<const float4 *>(Vp)[g4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < NLD; ++t) {
+            const int idx = lane + 64 * t;
+            if (idx < G4) reinterpret_cast<float4 *>(stage + buf * NC * FAST_D)[idx] = pre[t];
+        }
+    };
+
+    int buf = 0;
+    if (v0 < v1) { gload(clip_off[v0]); swrite(0); }
+
+    for (int v = v0; v < v1; ++v) {
+        const int c0 = clip_off[v], n = EXACT ? NT : clip_off[v + 1] - c0;
+        const int64_t mbase = mom_off[v];
+        const int ng = (n + NC - 1) / NC;
+        if (TOPK) {
+            // a video can append up to M = n(n+1)/2 keys per lane: make room first (CAP >= k + M by construction)
+            if (__ballot(cnt > CAP - n * (n + 1) / 2)) {
+                __threadfence_block();
+                const unsigned long long before = thr;
+                lane_tighten(col, lane, a.k, &cnt, &thr);
+                __threadfence_block();
+                if (thr < before) {
+                    dirty = true;
+                    if (active) __hip_atomic_fetch_min(a.thr_global + qi, thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (((v - v0) & 7) == 0 && active) {          // thresholds published by other waves
+                const unsigned long long g = __hip_atomic_load(a.thr_global + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (g < thr) { thr = g; dirty = true; }
+            }
+            if (__ballot(dirty)) {
+                const float x = thr == KEY_MAX ? __builtin_inff() : __uint_as_float((unsigned)(thr >> 32));
+#pragma unroll
+                for (int L = 1; L <= NT; ++L) hix_t[L - 1] = active ? excl_bound(sum_bound<false>(x, L)) : 0u;
+                dirty = false;
+            }
+        }
+        // ---- clip distances, NC chains at a time, V rows broadcast from the staging buffer ----
+#pragma nounroll
+        for (int g = 0; g < ng; ++g) {
+            const int64_t next_row = g + 1 < ng ? (int64_t)c0 + (g + 1) * NC : (int64_t)c0 + n;   // next video's c0
+            gload(next_row);
+            const float4 *vt = reinterpret_cast<const float4 *>(stage + buf * NC * FAST_D);
+            const float2v e2 = {a.eps, a.eps};
+            float acc[NC];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) acc[i] = 0.0f;
+            // software pipeline over k: the NC broadcast reads of slice j4+1 are issued (and pinned there by the
+            // sched_barrier) before the 8*NC VALU ops of slice j4, so LDS latency hides under the arithmetic.
+            float4 cur[NC], nxt[NC];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) cur[i] = vt[i * ROW4];
+#pragma unroll
+            for (int j4 = 0; j4 < ROW4; ++j4) {
+                if (j4 + 1 < ROW4) {
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) nxt[i] = vt[i * ROW4 + j4 + 1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const float2v d01 = (float2v{cur[i].x, cur[i].y} - qp[2 * j4]) + e2;
+                    const float2v d23 = (float2v{cur[i].z, cur[i].w} - qp[2 * j4 + 1]) + e2;
+                    acc[i] = __builtin_fmaf(d01.x, d01.x, acc[i]);
+                    acc[i] = __builtin_fmaf(d01.y, d01.y, acc[i]);
+                    acc[i] = __builtin_fmaf(d23.x, d23.x, acc[i]);
+                    acc[i] = __builtin_fmaf(d23.y, d23.y, acc[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NC; ++i) cur[i] = nxt[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NC; ++i) ds[(g * NC + i) * 64 + lane] = __builtin_sqrtf(acc[i]);   // rows >= n: unused
+            buf ^= 1;
+            swrite(buf);
+        }
+        // ---- moment triangle, L-outer, fully unrolled: sums[] and the tables are static registers ----
+        float sums[NT];
+        bool tie = wide;
+#pragma unroll
+        for (int L = 1; L <= NT; ++L) {
+            unsigned hx[NRR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) hx[r] = lox[r][L - 1] + ((unsigned)(dl[r] >> (2 * (L - 1))) & 3u);
+#pragma unroll
+            for (int s = 0; s + L <= NT; ++s) {
+                if (EXACT || s + L <= n) {                 // wave-uniform
+                    const float de = ds[(s + L - 1) * 64 + lane];
+                    const float sum = L == 1 ? de : sums[s] + de;
+                    sums[s] = sum;
+                    const unsigned sb = __float_as_uint(sum);
+                    if (TOPK) {
+                        if (sb < hix_t[L - 1]) {             // rare after warm-up: exact score, key, append
+                            const float sc = sum / (float)L;
+                            const unsigned id = (unsigned)(a.id_base + mbase + moment_index(n, s, s + L - 1));
+                            const unsigned long long key = make_key(sc, id);
+                            if (key < thr) { col[(size_t)cnt * 64 + lane] = key; ++cnt; }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const bool below = sb < lox[r][L - 1];
+                        nlt[r] += below ? 1 : 0;
+                        tie = tie || ((sb < hx[r]) && !below);
+                    }
+                }
+            }
+            // keep the scheduler from hoisting later rows' LDS reads over this one (register pressure -> spills)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (NR == 0 || __ballot(tie) == 0) continue;
+
+        // ---- some lane has score == a rank key: re-walk this video exactly and break the ties by moment id ----
+#pragma nounroll
+        for (int s = 0; s < n; ++s) {
+            float sum = 0.0f;
+#pragma nounroll
+            for (int e = s; e < n; ++e) {
+                const float de = ds[e * 64 + lane];
+                sum = e == s ? de : sum + de;
+                const float sc = sum / (float)(e - s + 1);
+                const unsigned id = (unsigned)(a.id_base + mbase + moment_index(n, s, e));
+                for (int r = 0; r < NR; ++r)
+                    if (active && sc == rank_dist[r * a.Nq + qi] && id < (unsigned)rank_idx[r * a.Nq + qi]) nlt[r] += 1;
+            }
+        }
+    }
+
+    if (active)
+        for (int r = 0; r < NR; ++r)
+            if (nlt[r]) atomicAdd(reinterpret_cast<unsigned long long *>(a.count_lt + r * a.Nq + qi), (unsigned long long)nlt[r]);
+    if (TOPK) {
+        __threadfence_block();
+        lane_tighten(col, lane, a.k, &cnt, &thr);            // cut over-full columns close to k (merge sorts exactly)
+        __threadfence_block();
+        a.buf_cnt[(size_t)task * 64 + lane] = active ? cnt : 0;
+    }
+}
+
+template <int NT, bool EXACT>
+static void launch_fast_nt(const ScoreArgs &a, int kpl, dim3 grid, size_t lds, hipStream_t st)
+{
+#define VFR_FAST(KPL, NRV, TOPKV)                                                                                    \
+    hipLaunchKernelGGL((score_fast_kernel<NT, KPL, NRV, TOPKV, EXACT>), grid, dim3(64), lds, st, a.Q, a.V, a.clip_off, \
+                       a.mom_off, a.rank_dist, a.rank_idx, a)
+    // NT = 21 with top-k AND two rank keys does not fit the 256-register budget of 2 waves/SIMD (the unrolled
+    // triangle would spill into its hot loop): run the two spill-free specialisations back to back instead.
+    const bool split = NT > 6 && a.k > 0 && a.num_rank > 0;
+    if (a.k > 0) {
+        if (a.num_rank == 0 || split) { if (kpl == 4) VFR_FAST(4, 0, true); else VFR_FAST(8, 0, true); }
+        else if constexpr (NT <= 6)   { if (kpl == 4) VFR_FAST(4, 2, true); else VFR_FAST(8, 2, true); }
+    }
+    if (a.num_rank > 0 && (a.k == 0 || split)) VFR_FAST(4, 2, false);
+#undef VFR_FAST
+}
+
 // one wave per query: merge the per-chunk sorted lists into the final top-k
 template <int KPL>
 __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned long long *__restrict__ buf,
                                                                const int *__restrict__ buf_cnt, int num_groups,
-                                                               int num_chunks, int64_t Nq, int k,
+                                                               int num_chunks, int64_t Nq, int k, int cap_t,
+                                                               const unsigned long long *__restrict__ extra,
+                                                               unsigned long long *__restrict__ out_keys,
+                                                               unsigned long long *__restrict__ thr_seed,
                                                                float *__restrict__ out_dist,
                                                                int64_t *__restrict__ out_idx)
 {
@@ -320,7 +658,10 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
     for (int ch = 0; ch < num_chunks; ++ch) {
         const size_t slot = ((size_t)ch * num_groups + group) * 64 + ql;
         const int c = buf_cnt[slot];
-        const unsigned long long *src = buf + slot * CAP;
+        // cap_t > 0: the fast kernel's transposed columns [task][slot][lane]; else lane-major [task][lane][CAP]
+        const unsigned long long *src = cap_t > 0 ? buf + ((size_t)ch * num_groups + group) * 64 * cap_t + ql
+                                                  : buf + slot * CAP;
+        const size_t stride = cap_t > 0 ? 64 : 1;
         int off = 0;
         while (off < c) {
             if (fill == CAP) {            // full: sort, keep the k best (k < CAP, so this frees room)
@@ -334,7 +675,26 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
 #pragma unroll
             for (int i = 0; i < KPL; ++i) {
                 int e = i * 64 + lane;
-                if (e >= fill && e < fill + take) key[i] = src[off + e - fill];
+                if (e >= fill && e < fill + take) key[i] = src[(size_t)(off + e - fill) * stride];
+            }
+            fill += take; off += take;
+        }
+    }
+    if (extra) {                          // a pre-sorted k-list per query (the sample pre-pass), KEY_MAX padded
+        int off = 0;
+        while (off < k) {
+            if (fill == CAP) {
+                wave_sort<KPL>(key, lane);
+#pragma unroll
+                for (int i = 0; i < KPL; ++i)
+                    if (i * 64 + lane >= k) key[i] = KEY_MAX;
+                fill = k;
+            }
+            const int room = CAP - fill, take = (k - off) < room ? (k - off) : room;
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                int e = i * 64 + lane;
+                if (e >= fill && e < fill + take) key[i] = extra[q * k + off + e - fill];
             }
             fill += take; off += take;
         }
@@ -345,8 +705,12 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
         int e = i * 64 + lane;
         if (e < k) {
             const bool ok = key[i] != KEY_MAX;
-            out_dist[q * k + e] = ok ? __uint_as_float((unsigned)(key[i] >> 32)) : __builtin_inff();
-            out_idx[q * k + e] = ok ? (int64_t)(key[i] & 0xffffffffull) : -1;
+            if (out_keys) out_keys[q * k + e] = key[i];
+            if (thr_seed && e == k - 1) thr_seed[q] = key[i];          // k-th best of the sample (KEY_MAX if fewer)
+            if (out_dist) {
+                out_dist[q * k + e] = ok ? __uint_as_float((unsigned)(key[i] >> 32)) : __builtin_inff();
+                out_idx[q * k + e] = ok ? (int64_t)(key[i] & 0xffffffffull) : -1;
+            }
         }
     }
 }
@@ -436,8 +800,8 @@ __global__ __launch_bounds__(64) void score_own_kernel(const float *__restrict__
 static void plan_tasks(int64_t Nq, int Nv, int *groups, int *chunks)
 {
     int g = (int)cdiv(Nq, 64);
-    // aim for ~12 waves per CU on 256 CUs; never more chunks than videos
-    int64_t want = cdiv(3072, g);
+    // 2048 wave slots at 2 waves/SIMD: aim for ~4 full rounds so the tail round stays small
+    int64_t want = cdiv(8192, g);
     int c = (int)(want < 1 ? 1 : want);
     if (c > Nv) c = Nv < 1 ? 1 : Nv;
     if (c > 1024) c = 1024;
@@ -446,28 +810,56 @@ static void plan_tasks(int64_t Nq, int Nv, int *groups, int *chunks)
 }
 static int kpl_for(int k) { return k <= 128 ? 4 : 8; }
 
-struct TopkWs { unsigned long long *buf; int *cnt; unsigned long long *thr; size_t total; };
+constexpr int PRE_VIDEOS = 256;     // sample scored exactly first; its k-th best key seeds every query's threshold
+constexpr int PRE_CHUNKS = 26;      // ~10 sample videos per wave-task
+
+struct TopkWs { unsigned long long *buf, *buf_pre, *pre_keys; int *cnt, *cnt_pre; unsigned long long *thr; size_t total; };
 static TopkWs carve_topk(void *base, int64_t Nq, int Nv, int k)
 {
     TopkWs w{};
     int g, c;
     plan_tasks(Nq, Nv, &g, &c);
-    size_t tasks = (size_t)g * c, cap = (size_t)kpl_for(k) * 64, off = 0;
+    size_t tasks = (size_t)g * c, tasks_pre = (size_t)g * PRE_CHUNKS, cap = 512, off = 0;   // cap: largest either kernel uses
     auto take = [&](size_t bytes) { char *p = static_cast<char *>(base) + off; off += align_up(bytes, 256); return p; };
     w.thr = reinterpret_cast<unsigned long long *>(take((size_t)Nq * 8));
     w.cnt = reinterpret_cast<int *>(take(tasks * 64 * 4));
+    w.cnt_pre = reinterpret_cast<int *>(take(tasks_pre * 64 * 4));
+    w.pre_keys = reinterpret_cast<unsigned long long *>(take(k > 0 ? (size_t)Nq * k * 8 : 0));
+    w.buf_pre = reinterpret_cast<unsigned long long *>(take(k > 0 ? tasks_pre * 64 * cap * 8 : 0));
     w.buf = reinterpret_cast<unsigned long long *>(take(k > 0 ? tasks * 64 * cap * 8 : 0));
     w.total = off;
     return w;
 }
 
-template <int MODE>
-static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st)
+static bool fast_applicable(const ScoreArgs &a)
 {
+    const int NT = a.ds_rows <= 6 ? 6 : 21, M = NT * (NT + 1) / 2;
+    return a.D == FAST_D && opt_score_fast() && (a.num_rank == 0 || a.num_rank == 2) && (a.k > 0 || a.num_rank > 0) &&
+           (a.ds_rows <= 6 || a.ds_rows == 21) && a.k + M <= 512;
+}
+
+template <int MODE>
+static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st, int *cap_transposed = nullptr)
+{
+    if (cap_transposed) *cap_transposed = 0;
     const int tasks = a.num_groups * a.num_chunks;
+    ProfScope prof(MODE == 0 ? SITE_SCORE_DENSE : SITE_SCORE_FUSED, st);
+    const int NTsel = a.ds_rows <= 6 ? 6 : 21, Msel = NTsel * (NTsel + 1) / 2;
+    if (MODE == 1 && fast_applicable(a) && !a.force_generic) {
+        const int NT = NTsel;
+        kpl = a.k + Msel <= 256 ? 4 : 8;                   // candidate columns hold k kept + one video's worth
+        if (cap_transposed && a.k > 0) *cap_transposed = kpl * 64;
+        const bool exact = a.min_clips == NT;              // every video has exactly NT clips: no length guards
+        const int NCg = NT == 6 ? 3 : 4, rows = (NT + NCg - 1) / NCg * NCg;
+        const size_t lds = ((size_t)2 * NCg * FAST_D + (size_t)rows * 64) * sizeof(float);
+        dim3 grid((unsigned)tasks);
+        if (NT == 6) { if (exact) launch_fast_nt<6, true>(a, kpl, grid, lds, st); else launch_fast_nt<6, false>(a, kpl, grid, lds, st); }
+        else         { if (exact) launch_fast_nt<21, true>(a, kpl, grid, lds, st); else launch_fast_nt<21, false>(a, kpl, grid, lds, st); }
+        VFR_CHECK_LAUNCH("score_fast_kernel");
+        return VFR_OK;
+    }
     const size_t lds = (size_t)4 * a.ds_rows * 64 * sizeof(float);
     dim3 grid((unsigned)cdiv(tasks, 4)), block(256);
-    ProfScope prof(MODE == 0 ? SITE_SCORE_DENSE : SITE_SCORE_FUSED, st);
 #define VFR_LAUNCH(DT, KPL)                                                                              \
     hipLaunchKernelGGL((score_kernel<DT, MODE, KPL>), grid, block, lds, st, a.Q, a.V, a.clip_off, a.mom_off, \
                        a.rank_dist, a.rank_idx, a)
@@ -494,6 +886,7 @@ int vfr_score_moments_f32(const float *Q, int64_t Nq, const float *V, const int3
     vfr::ScoreArgs a{};
     a.Q = Q; a.Nq = Nq; a.V = V; a.clip_off = clip_offsets; a.mom_off = moment_offsets; a.Nv = Nv; a.D = D; a.eps = eps;
     a.scores = scores; a.total_moments = total_moments; a.ds_rows = max_clips < 1 ? 1 : max_clips;
+    a.v_lo = 0; a.v_hi = Nv;
     vfr::plan_tasks(Nq, Nv, &a.num_groups, &a.num_chunks);
     return vfr::launch_score<0>(a, 4, vfr::as_stream(stream));
 }
@@ -521,16 +914,16 @@ size_t vfr_score_topk_workspace_bytes(int64_t Nq, int Nv, int k)
 }
 
 int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets,
-                       const int64_t *moment_offsets, int Nv, int total_clips, int max_clips, int D, float eps,
-                       int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
+                       const int64_t *moment_offsets, int Nv, int total_clips, int min_clips, int max_clips, int D,
+                       float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
                        const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, void *workspace,
                        size_t workspace_bytes, vfr_stream_t stream)
 {
-    (void)total_clips;
     VFR_REQUIRE(num_rank >= 0 && num_rank <= vfr::MAX_RANK, VFR_EUNSUPPORTED, "vfr_score_topk_f32: num_rank=%d > %d",
                 num_rank, vfr::MAX_RANK);
     if (num_rank == 0) { rank_dist = nullptr; rank_idx = nullptr; }
-    VFR_REQUIRE(Q && V && clip_offsets && moment_offsets && Nq >= 0 && Nv >= 0 && D > 0 && k >= 0 && id_base >= 0,
+    VFR_REQUIRE(Q && V && clip_offsets && moment_offsets && Nq >= 0 && Nv >= 0 && D > 0 && k >= 0 && id_base >= 0 &&
+                    total_clips >= 0,
                 VFR_EINVAL, "vfr_score_topk_f32: bad argument");
     VFR_REQUIRE(k == 0 || (out_dist && out_idx), VFR_EINVAL, "vfr_score_topk_f32: k > 0 needs out_dist/out_idx");
     VFR_REQUIRE(num_rank == 0 || (rank_dist && rank_idx && count_lt), VFR_EINVAL,
@@ -548,25 +941,58 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
     a.Q = Q; a.Nq = Nq; a.V = V; a.clip_off = clip_offsets; a.mom_off = moment_offsets; a.Nv = Nv; a.D = D; a.eps = eps;
     a.id_base = id_base; a.k = k; a.num_rank = num_rank; a.rank_dist = rank_dist; a.rank_idx = rank_idx; a.count_lt = count_lt;
     a.buf = w.buf; a.buf_cnt = w.cnt; a.thr_global = w.thr; a.ds_rows = max_clips < 1 ? 1 : max_clips;
+    a.total_clips = total_clips;
+    a.min_clips = min_clips;
+    a.v_lo = 0; a.v_hi = Nv;
     vfr::plan_tasks(Nq, Nv, &a.num_groups, &a.num_chunks);
     const int kpl = vfr::kpl_for(k);
+    int cap_t = 0, cap_pre = 0;
+    const unsigned long long *extra = nullptr;
+    auto merge = [&](const unsigned long long *buf, const int *cnt, int chunks, int capt, const unsigned long long *ex,
+                     unsigned long long *okeys, unsigned long long *seed, float *od, int64_t *oi) {
+        dim3 grid((unsigned)vfr::cdiv(Nq, 4)), block(256);
+        if (kpl == 4)
+            hipLaunchKernelGGL((vfr::topk_merge_tasks_kernel<4>), grid, block, 0, st, buf, cnt, a.num_groups, chunks, Nq, k,
+                               capt, ex, okeys, seed, od, oi);
+        else
+            hipLaunchKernelGGL((vfr::topk_merge_tasks_kernel<8>), grid, block, 0, st, buf, cnt, a.num_groups, chunks, Nq, k,
+                               capt, ex, okeys, seed, od, oi);
+    };
     if (Nv > 0) {
         if (k > 0 && hipMemsetAsync(w.thr, 0xFF, (size_t)Nq * 8, st) != hipSuccess)
             return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: hipMemsetAsync failed");
-        if (int rc = vfr::launch_score<1>(a, kpl, st)) return rc;
+        // sample pre-pass (fast path only, corpus large enough): exact top-k of the first PRE_VIDEOS videos; its k-th
+        // key seeds thr_global, so the main pass appends ~k*Nv/PRE_VIDEOS candidates per query and never has to
+        // tighten.  The rank counters always run over the whole range in the main launch.
+        const bool prepass = k > 0 && vfr::fast_applicable(a) && Nv >= 8 * vfr::PRE_VIDEOS;
+        if (prepass) {
+            vfr::ScoreArgs pre = a;
+            pre.v_lo = 0; pre.v_hi = vfr::PRE_VIDEOS; pre.num_chunks = vfr::PRE_CHUNKS; pre.num_rank = 0;
+            pre.rank_dist = nullptr; pre.rank_idx = nullptr; pre.buf = w.buf_pre; pre.buf_cnt = w.cnt_pre;
+            pre.force_generic = 1;      // warm-up heavy, tiny: the cooperative-sort kernel handles it best
+            if (int rc = vfr::launch_score<1>(pre, kpl, st, &cap_pre)) return rc;
+            {
+                vfr::ProfScope prof(vfr::SITE_TOPK_MERGE, st);
+                merge(w.buf_pre, w.cnt_pre, vfr::PRE_CHUNKS, cap_pre, nullptr, w.pre_keys, w.thr, nullptr, nullptr);
+            }
+            VFR_CHECK_LAUNCH("topk_merge_tasks_kernel(pre)");
+            extra = w.pre_keys;
+            if (num_rank > 0) {                         // ranks over everything, top-k over the rest
+                vfr::ScoreArgs rk = a;
+                rk.k = 0;
+                if (int rc = vfr::launch_score<1>(rk, kpl, st)) return rc;
+                a.num_rank = 0; a.rank_dist = nullptr; a.rank_idx = nullptr;
+            }
+            a.v_lo = vfr::PRE_VIDEOS;
+        }
+        if (int rc = vfr::launch_score<1>(a, kpl, st, &cap_t)) return rc;
     } else if (k > 0) {
         if (hipMemsetAsync(w.cnt, 0, (size_t)a.num_groups * a.num_chunks * 64 * 4, st) != hipSuccess)
             return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: hipMemsetAsync failed");
     }
     if (k > 0) {
         vfr::ProfScope prof(vfr::SITE_TOPK_MERGE, st);
-        dim3 grid((unsigned)vfr::cdiv(Nq, 4)), block(256);
-        if (kpl == 4)
-            hipLaunchKernelGGL((vfr::topk_merge_tasks_kernel<4>), grid, block, 0, st, w.buf, w.cnt, a.num_groups,
-                               a.num_chunks, Nq, k, out_dist, out_idx);
-        else
-            hipLaunchKernelGGL((vfr::topk_merge_tasks_kernel<8>), grid, block, 0, st, w.buf, w.cnt, a.num_groups,
-                               a.num_chunks, Nq, k, out_dist, out_idx);
+        merge(w.buf, w.cnt, a.num_chunks, cap_t, extra, nullptr, nullptr, out_dist, out_idx);
         VFR_CHECK_LAUNCH("topk_merge_tasks_kernel");
     }
     return VFR_OK;

@@ -11,6 +11,7 @@ namespace vfr {
 static thread_local char g_err[512] = "";
 static int g_opt_gemm = 1;
 static int g_opt_profile = 0;
+static int g_opt_score_fast = 1;
 
 struct ProfPair { int site; hipEvent_t a, b; };
 static std::vector<ProfPair> g_pairs;          // recorded, not yet read
@@ -53,6 +54,7 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 int opt_gemm() { return g_opt_gemm; }
+int opt_score_fast() { return g_opt_score_fast; }
 
 __global__ void math_probe_kernel(int op, const float *x, const float *y, float *out, int64_t n)
 {
@@ -82,12 +84,14 @@ int vfr_set_option(const char *name, int value)
 {
     if (name && !strcmp(name, "gemm")) { vfr::g_opt_gemm = value; return VFR_OK; }
     if (name && !strcmp(name, "profile")) { vfr::g_opt_profile = value; return VFR_OK; }
+    if (name && !strcmp(name, "score_fast")) { vfr::g_opt_score_fast = value; return VFR_OK; }
     return vfr::fail(VFR_EINVAL, "vfr_set_option: unknown option '%s'", name ? name : "(null)");
 }
 int vfr_get_option(const char *name)
 {
     if (name && !strcmp(name, "gemm")) return vfr::g_opt_gemm;
     if (name && !strcmp(name, "profile")) return vfr::g_opt_profile;
+    if (name && !strcmp(name, "score_fast")) return vfr::g_opt_score_fast;
     return vfr::fail(VFR_EINVAL, "vfr_get_option: unknown option '%s'", name ? name : "(null)");
 }
 

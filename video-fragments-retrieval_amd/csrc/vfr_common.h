@@ -17,6 +17,7 @@ inline hipStream_t as_stream(vfr_stream_t s) { return reinterpret_cast<hipStream
 
 // option switches (vfr_set_option)
 int opt_gemm();
+int opt_score_fast();
 
 // ---- launch-site profiler (vfr_set_option("profile", 1)): HIP events recorded on the launch stream
 // around every instrumented launch; vfr_profile_read() turns them into per-site totals after a sync.
