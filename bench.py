@@ -57,13 +57,17 @@ def site_work(site, cfg):
     B, C, Nv, H, E, F, hid, D, n, Nq = (cfg[k] for k in ("Bq", "C", "Nv", "H", "E", "F", "hid", "D", "n", "Nq"))
     M = n * (n + 1) // 2
     table = {
-        "gemm_lstm_rec": 2.0 * B * 4 * H * H,
-        "gemm_lstm_in": 2.0 * B * cfg["T"] * 4 * H * E,
+        "gemm_lstm_rec": 2.0 * 2 * B * 4 * H * H,             # forward + reverse launched as one grid
+        "gemm_lstm_in": 2.0 * 2 * B * cfg["T"] * 4 * H * E,
         "gemm_vis_seg": 2.0 * C * hid * F,
         "gemm_vis_ctx": 2.0 * Nv * hid * F,
         "gemm_vis_out": 2.0 * C * D * hid,
         "gemm_lang_fc": 2.0 * B * D * 2 * H,
-        "score_fused": float(Nq) * Nv * (2 * n * D + n + 2 * M),
+        # scoring launches (2nD contraction + n norms + 2M moment means per scoring); the sample
+        # pre-pass covers 256 videos, the top-k launch the rest, the rank launch everything
+        "score_fused": float(Nq) * max(Nv - 256, 0) * (2 * n * D + n + 2 * M),
+        "score_rank": float(Nq) * Nv * (2 * n * D + n + 2 * M),
+        "score_prepass": float(Nq) * min(Nv, 256) * (2 * n * D + n + 2 * M),
     }
     return table.get(site)
 

@@ -60,7 +60,7 @@ int vfr_segment_pool_norm_batch_f32(const float *frames, const int32_t *frame_of
  * branch model/models.py:21-26,55-56.  Row t of video v is [seg_t | ctx_v | t/n | (t+1)/n] x
  * W1[hid, 2F+2] -> ReLU -> W2[D, hid]; the 2F+2 concat is never materialised and the context
  * half of W1 is applied once per video.  clip_offsets [Nv+1] int32; out [total_clips, D].       */
-size_t vfr_visual_mlp_workspace_bytes(int total_clips, int Nv, int hid);
+size_t vfr_visual_mlp_workspace_bytes(int total_clips, int Nv, int F, int hid);
 int vfr_visual_mlp_f32(const float *seg, const float *ctx, const int32_t *clip_offsets, int Nv, int total_clips,
                        int F, const float *W1, const float *b1, const float *W2, const float *b2, int hid, int D,
                        float *out, void *workspace, size_t workspace_bytes, vfr_stream_t stream);

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Time the chain GEMM (vfr_linear_f32) at the hot shapes.  usage: gemm_bench.py [reps]"""
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import vfr_amd  # noqa
+from vfr_amd import _vfr
+
+dev = "cuda:0"
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+torch.manual_seed(0)
+for name, M, K, N in (("lstm_rec  [5000x1000]x[4000x1000]^T", 5000, 1000, 4000), ("vis_seg  [210000x4096]x[500x4096]^T", 210000, 4096, 500),
+                      ("square 4096^3", 4096, 4096, 4096)):
+    A = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev)
+    _vfr.linear(A, W); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        _vfr.linear(A, W)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / reps * 1e3
+    print(f"{name:40s} {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:7.1f} TFLOP/s", flush=True)

@@ -40,9 +40,9 @@ sub = _vfr.VideoBank(V[(nv // 2) * n:(nv // 2 + 1) * n].contiguous(), off[:2].co
 mid_d = _vfr.score_moments(Q, sub)[:, 0].contiguous()   # a typical (median-ish) distance as rank key
 mid_d = torch.stack([mid_d, mid_d * 1.001]).contiguous()
 
-for fast in (1, 0):
-    _vfr.set_option("score_fast", fast)
-    tag = "fast" if fast else "v1  "
+for fast in (1, 2, 0):
+    _vfr.set_option("score_fast", 1 if fast else 0); _vfr.set_option("score_split", 1 if fast == 2 else 0)
+    tag = {1: "fused", 2: "split", 0: "v1   "}[fast]
     timed(f"[{tag}] top-100 only", lambda: _vfr.score_topk(Q, bank, 100, workspace=ws))
     timed(f"[{tag}] rank x2 only (selective keys)", lambda: _vfr.score_topk(Q, bank, 0, rd, ri, workspace=ws))
     timed(f"[{tag}] rank x2 only (median keys)", lambda: _vfr.score_topk(Q, bank, 0, mid_d, mid_id, workspace=ws))

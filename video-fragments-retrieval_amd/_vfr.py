@@ -32,7 +32,7 @@ SIGNATURES = {
     "vfr_math_f32": (_i32, [_i32, _vp, _vp, _vp, _i64, _vp]),
     "vfr_segment_pool_norm_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "vfr_segment_pool_norm_batch_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "vfr_visual_mlp_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "vfr_visual_mlp_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "vfr_visual_mlp_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vfr_linear_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     "vfr_bilstm_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
@@ -167,7 +167,7 @@ def visual_mlp(seg, ctx, clip_off, W1, b1, W2, b2) -> torch.Tensor:
     if W1.shape[1] != 2 * F + 2 or clip_off.numel() != Nv + 1 or W2.shape[1] != hid:
         raise RuntimeError("visual_mlp: inconsistent shapes")
     out = torch.empty((C, D), dtype=torch.float32, device=seg.device)
-    ws_bytes = lib().vfr_visual_mlp_workspace_bytes(C, Nv, hid)
+    ws_bytes = lib().vfr_visual_mlp_workspace_bytes(C, Nv, F, hid)
     ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=seg.device)
     _check(lib().vfr_visual_mlp_f32(seg.data_ptr(), ctx.data_ptr(), clip_off.data_ptr(), Nv, C, F, W1.data_ptr(),
                                     b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), hid, D, out.data_ptr(), ws.data_ptr(),

@@ -109,25 +109,28 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
                        emb, len_tab, E, w.X);
     }
     VFR_CHECK_LAUNCH("embed_kernel");
-    for (int d = 0; d < 2; ++d) {
-        vfr::GemmArgs g{};
-        g.A = w.X; g.lda = E; g.W = Wih[d]; g.ldw = E; g.out = w.gin[d]; g.ldo = G; g.M = B * T; g.N = G; g.K = E;
-        g.bias = bih[d]; g.bias2 = bhh[d]; g.epi = vfr::EPI_BIAS2; g.site = vfr::SITE_GEMM_LSTM_IN;
-        if (int rc = vfr::gemm_nt(g, st)) return rc;
+    {
+        vfr::GemmArgs g[2]{};
+        for (int d = 0; d < 2; ++d) {
+            g[d].A = w.X; g[d].lda = E; g[d].W = Wih[d]; g[d].ldw = E; g[d].out = w.gin[d]; g[d].ldo = G; g[d].M = B * T;
+            g[d].N = G; g[d].K = E; g[d].bias = bih[d]; g[d].bias2 = bhh[d]; g[d].epi = vfr::EPI_BIAS2;
+            g[d].site = vfr::SITE_GEMM_LSTM_IN;
+        }
+        if (int rc = vfr::gemm_nt_pair(g[0], g[1], st)) return rc;
     }
     if (hipMemsetAsync(w.c, 0, (size_t)2 * B * H * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(w.hcat, 0, (size_t)B * 2 * H * sizeof(float), st) != hipSuccess)
         return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: hipMemsetAsync failed");
     for (int step = 0; step < T; ++step) {
+        vfr::GemmArgs g[2]{};
         for (int d = 0; d < 2; ++d) {
             const int t = d ? T - 1 - step : step;
-            vfr::GemmArgs g{};
-            g.A = w.hcat + (size_t)d * H; g.lda = 2 * H; g.W = Whh[d]; g.ldw = H;
-            g.Cin = w.gin[d] + (size_t)t * G; g.ldc = (int64_t)T * G;
-            g.out = w.gates + (size_t)d * B * G; g.ldo = G; g.M = B; g.N = G; g.K = H;
-            g.site = vfr::SITE_GEMM_LSTM_REC;
-            if (int rc = vfr::gemm_nt(g, st)) return rc;
+            g[d].A = w.hcat + (size_t)d * H; g[d].lda = 2 * H; g[d].W = Whh[d]; g[d].ldw = H;
+            g[d].Cin = w.gin[d] + (size_t)t * G; g[d].ldc = (int64_t)T * G;
+            g[d].out = w.gates + (size_t)d * B * G; g[d].ldo = G; g[d].M = B; g[d].N = G; g[d].K = H;
+            g[d].site = vfr::SITE_GEMM_LSTM_REC;
         }
+        if (int rc = vfr::gemm_nt_pair(g[0], g[1], st)) return rc;      // forward + reverse as one grid
         {
         vfr::ProfScope prof(vfr::SITE_LSTM_POINTWISE, st);
         hipLaunchKernelGGL(vfr::lstm_pointwise_kernel, dim3((unsigned)vfr::cdiv(2 * B * H, 256)), dim3(256), 0, st,

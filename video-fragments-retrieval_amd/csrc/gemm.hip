@@ -105,11 +105,13 @@ __device__ __forceinline__ float4 load4_guard(const float *__restrict__ P, int64
     return r;
 }
 
+struct GemmPair { GemmArgs p[2]; };
+
 template <bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_nt_mfma(GemmArgs g)
+__device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
-    __shared__ __attribute__((aligned(16))) float As[MBM * MLD];
-    __shared__ __attribute__((aligned(16))) float Ws[MBN * MLD];
+    // double-buffered tiles: [2][A 128x36 | W 128x36] floats = 73,728 B -> two workgroups per CU
+    __shared__ __attribute__((aligned(16))) float lds[2 * (MBM + MBN) * MLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * MBM;
@@ -128,15 +130,41 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma(GemmArgs g)
             }
 
     float4 ra[4], rw[4];
-    auto gload = [&](int k0) {
+    // Staging loads.  Full K-tiles use UNCONDITIONAL loads (row index clamped into range; rows past M / N are
+    // never stored) so the compiler can leave them in flight across the MFMA block -- a per-load bounds branch
+    // makes hipcc drain vmcnt(0) right after issuing them.  Only the last, partial K-tile takes the guarded form.
+    const float *arow[4], *wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
+        const int64_t ma = m0 + row < g.M ? m0 + row : g.M - 1;
+        const int64_t nw = (int64_t)n0 + row < g.N ? (int64_t)n0 + row : g.N - 1;
+        arow[i] = g.A + ma * g.lda + kk;
+        wrow[i] = g.W + nw * g.ldw + kk;
+    }
+    auto gload_full = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (VEC) {
+                ra[i] = *reinterpret_cast<const float4 *>(arow[i] + k0);
+                rw[i] = *reinterpret_cast<const float4 *>(wrow[i] + k0);
+            } else {
+                ra[i] = make_float4(arow[i][k0], arow[i][k0 + 1], arow[i][k0 + 2], arow[i][k0 + 3]);
+                rw[i] = make_float4(wrow[i][k0], wrow[i][k0 + 1], wrow[i][k0 + 2], wrow[i][k0 + 3]);
+            }
+        }
+    };
+    auto gload_tail = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
-            ra[i] = load4_guard<VEC>(g.A, g.lda, m0 + row, g.M, k0 + kk, g.K);
-            rw[i] = load4_guard<VEC>(g.W, g.ldw, (int64_t)n0 + row, g.N, k0 + kk, g.K);
+            ra[i] = load4_guard<false>(g.A, g.lda, m0 + row, g.M, k0 + kk, g.K);
+            rw[i] = load4_guard<false>(g.W, g.ldw, (int64_t)n0 + row, g.N, k0 + kk, g.K);
         }
     };
-    auto swrite = [&]() {
+    const int nk_full = g.K / MBK;
+    auto swrite = [&](int b) {
+        float *As = lds + b * (MBM + MBN) * MLD, *Ws = As + MBM * MLD;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
@@ -144,14 +172,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma(GemmArgs g)
             *reinterpret_cast<float4 *>(&Ws[row * MLD + kk]) = rw[i];
         }
     };
-
-    const int nk = (g.K + MBK - 1) / MBK;
-    if (nk > 0) { gload(0); swrite(); }
-    __syncthreads();
-    const float *ap = &As[(wm * 64 + l31) * MLD];
-    const float *wp = &Ws[(wn * 64 + l31) * MLD];
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload((kt + 1) * MBK);
+    auto compute = [&](int b) {
+        const float *As = lds + b * (MBM + MBN) * MLD, *Ws = As + MBM * MLD;
+        const float *ap = &As[(wm * 64 + l31) * MLD];
+        const float *wp = &Ws[(wn * 64 + l31) * MLD];
 #pragma unroll
         for (int k4 = 0; k4 < MBK / 4; ++k4) {
             const float4 a0 = *reinterpret_cast<const float4 *>(ap + k4 * 4);
@@ -173,8 +197,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma(GemmArgs g)
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc[1][1], 0, 0, 0);
             }
         }
+    };
+
+    // main loop over the FULL K-tiles, branch-free: iteration kt prefetches tile min(kt+1, last) (the final
+    // iteration re-reads its own tile, which is harmless) so no control-flow join sits between the loads and the
+    // MFMA block -- a join there makes the compiler drain vmcnt(0) before the first MFMA.
+    if (nk_full > 0) { gload_full(0); swrite(0); }
+    __syncthreads();
+    for (int kt = 0; kt < nk_full; ++kt) {
+        const int nxt = kt + 1 < nk_full ? kt + 1 : nk_full - 1;
+        gload_full(nxt * MBK);
+        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
+        compute(kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // the other buffer was last read in iteration kt-1 and every wave has passed that iteration's barrier:
+        // refill it now (overlapping the other waves' MFMAs); one barrier per K-tile
+        swrite((kt + 1) & 1);
         __syncthreads();
-        if (kt + 1 < nk) { swrite(); __syncthreads(); }
+    }
+    if (g.K % MBK) {                       // partial last tile: guarded loads, zero padded (fma(0,0,acc) == acc)
+        gload_tail(nk_full * MBK);
+        swrite(nk_full & 1);
+        __syncthreads();
+        compute(nk_full & 1);
     }
 
 #pragma unroll
@@ -198,6 +243,53 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma(GemmArgs g)
         }
 }
 
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_nt_mfma(GemmArgs g) { gemm_nt_mfma_body<VEC>(g); }
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp) { gemm_nt_mfma_body<VEC>(gp.p[blockIdx.z]); }
+
+__global__ __launch_bounds__(256) void repack_rows_kernel(const float *__restrict__ src, int64_t ld_src, int rows, int cols,
+                                                          float *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    dst[i] = src[r * ld_src + c];
+}
+
+int repack_rows(const float *src, int64_t ld_src, int rows, int cols, float *dst, hipStream_t st)
+{
+    if (rows <= 0 || cols <= 0) return VFR_OK;
+    ProfScope prof(SITE_REPACK, st);
+    hipLaunchKernelGGL(repack_rows_kernel, dim3((unsigned)cdiv((int64_t)rows * cols, 256)), dim3(256), 0, st, src, ld_src, rows,
+                       cols, dst);
+    VFR_CHECK_LAUNCH("repack_rows_kernel");
+    return VFR_OK;
+}
+
+static bool gemm_vec_ok(const GemmArgs &g)
+{
+    return ((g.lda | g.ldw) & 3) == 0 && ((((uintptr_t)g.A) | ((uintptr_t)g.W)) & 15) == 0;
+}
+
+int gemm_nt_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
+{
+    if (opt_gemm() == 0 || g0.M != g1.M || g0.N != g1.N || g0.K != g1.K || g0.epi != g1.epi) {
+        if (int rc = gemm_nt(g0, st)) return rc;
+        return gemm_nt(g1, st);
+    }
+    if (g0.M == 0 || g0.N == 0) return VFR_OK;
+    VFR_REQUIRE(g0.A && g0.W && g0.out && g1.A && g1.W && g1.out, VFR_EINVAL, "gemm_nt_pair: bad argument");
+    ProfScope prof(g0.site, st);
+    GemmPair gp{{g0, g1}};
+    dim3 grid((unsigned)cdiv(g0.M, MBM), (unsigned)cdiv(g0.N, MBN), 2);
+    if (gemm_vec_ok(g0) && gemm_vec_ok(g1)) hipLaunchKernelGGL(gemm_nt_mfma_pair<true>, grid, dim3(256), 0, st, gp);
+    else                                    hipLaunchKernelGGL(gemm_nt_mfma_pair<false>, grid, dim3(256), 0, st, gp);
+    VFR_CHECK_LAUNCH("gemm_nt_mfma_pair");
+    return VFR_OK;
+}
+
 int gemm_nt(const GemmArgs &g, hipStream_t st)
 {
     if (g.M == 0 || g.N == 0) return VFR_OK;
@@ -211,7 +303,7 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
         VFR_CHECK_LAUNCH("gemm_nt_valu");
         return VFR_OK;
     }
-    const bool vec = ((g.lda | g.ldw) & 3) == 0 && ((((uintptr_t)g.A) | ((uintptr_t)g.W)) & 15) == 0;
+    const bool vec = gemm_vec_ok(g);
     dim3 grid((unsigned)cdiv(g.M, MBM), (unsigned)cdiv(g.N, MBN));
     if (vec) hipLaunchKernelGGL(gemm_nt_mfma<true>, grid, dim3(256), 0, st, g);
     else     hipLaunchKernelGGL(gemm_nt_mfma<false>, grid, dim3(256), 0, st, g);

@@ -413,7 +413,7 @@ template <> struct FastCfg<6> { static constexpr int NC = 3; };
 __device__ __forceinline__ unsigned excl_bound(float s) { return s < 0.0f ? 0u : __float_as_uint(s) + 1u; }
 
 template <int NT, int KPL, int NR, bool TOPK, bool EXACT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NT > 6 && NR > 0 && TOPK) ? 1 : 2, 8)))
 void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ Vp, const int32_t *__restrict__ clip_off,
                        const int64_t *__restrict__ mom_off, const float *__restrict__ rank_dist,
                        const int64_t *__restrict__ rank_idx, ScoreArgs a)
@@ -624,12 +624,13 @@ static void launch_fast_nt(const ScoreArgs &a, int kpl, dim3 grid, size_t lds, h
 #define VFR_FAST(KPL, NRV, TOPKV)                                                                                    \
     hipLaunchKernelGGL((score_fast_kernel<NT, KPL, NRV, TOPKV, EXACT>), grid, dim3(64), lds, st, a.Q, a.V, a.clip_off, \
                        a.mom_off, a.rank_dist, a.rank_idx, a)
-    // NT = 21 with top-k AND two rank keys does not fit the 256-register budget of 2 waves/SIMD (the unrolled
-    // triangle would spill into its hot loop): run the two spill-free specialisations back to back instead.
-    const bool split = NT > 6 && a.k > 0 && a.num_rank > 0;
+    // NT = 21 with top-k AND two rank keys needs more than the 256 registers of 2 waves/SIMD: that instantiation is
+    // built for 1 wave/SIMD (512-register budget, no spills).  vfr_set_option("score_split", 1) runs the two
+    // spill-free 2-waves/SIMD specialisations back to back instead (kept for A/B measurements).
+    const bool split = NT > 6 && a.k > 0 && a.num_rank > 0 && opt_score_split();
     if (a.k > 0) {
         if (a.num_rank == 0 || split) { if (kpl == 4) VFR_FAST(4, 0, true); else VFR_FAST(8, 0, true); }
-        else if constexpr (NT <= 6)   { if (kpl == 4) VFR_FAST(4, 2, true); else VFR_FAST(8, 2, true); }
+        else                          { if (kpl == 4) VFR_FAST(4, 2, true); else VFR_FAST(8, 2, true); }
     }
     if (a.num_rank > 0 && (a.k == 0 || split)) VFR_FAST(4, 2, false);
 #undef VFR_FAST
@@ -843,7 +844,7 @@ static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st, int *cap_tr
 {
     if (cap_transposed) *cap_transposed = 0;
     const int tasks = a.num_groups * a.num_chunks;
-    ProfScope prof(MODE == 0 ? SITE_SCORE_DENSE : SITE_SCORE_FUSED, st);
+    ProfScope prof(MODE == 0 ? SITE_SCORE_DENSE : a.force_generic ? SITE_SCORE_PREPASS : a.k == 0 ? SITE_SCORE_RANK : SITE_SCORE_FUSED, st);
     const int NTsel = a.ds_rows <= 6 ? 6 : 21, Msel = NTsel * (NTsel + 1) / 2;
     if (MODE == 1 && fast_applicable(a) && !a.force_generic) {
         const int NT = NTsel;
@@ -977,11 +978,13 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
             }
             VFR_CHECK_LAUNCH("topk_merge_tasks_kernel(pre)");
             extra = w.pre_keys;
-            if (num_rank > 0) {                         // ranks over everything, top-k over the rest
+            if (num_rank > 0) {                         // the rank counters must see the sample videos too
                 vfr::ScoreArgs rk = a;
                 rk.k = 0;
+                const bool fused_main = !(vfr::opt_score_split() && a.ds_rows > 6);
+                if (fused_main) rk.v_hi = vfr::PRE_VIDEOS;     // ranks of the sample here, the rest fused with top-k
                 if (int rc = vfr::launch_score<1>(rk, kpl, st)) return rc;
-                a.num_rank = 0; a.rank_dist = nullptr; a.rank_idx = nullptr;
+                if (!fused_main) { a.num_rank = 0; a.rank_dist = nullptr; a.rank_idx = nullptr; }
             }
             a.v_lo = vfr::PRE_VIDEOS;
         }

@@ -12,6 +12,7 @@ static thread_local char g_err[512] = "";
 static int g_opt_gemm = 1;
 static int g_opt_profile = 0;
 static int g_opt_score_fast = 1;
+static int g_opt_score_split = 1;
 
 struct ProfPair { int site; hipEvent_t a, b; };
 static std::vector<ProfPair> g_pairs;          // recorded, not yet read
@@ -55,6 +56,7 @@ int fail(int code, const char *fmt, ...)
 }
 int opt_gemm() { return g_opt_gemm; }
 int opt_score_fast() { return g_opt_score_fast; }
+int opt_score_split() { return g_opt_score_split; }
 
 __global__ void math_probe_kernel(int op, const float *x, const float *y, float *out, int64_t n)
 {
@@ -85,6 +87,7 @@ int vfr_set_option(const char *name, int value)
     if (name && !strcmp(name, "gemm")) { vfr::g_opt_gemm = value; return VFR_OK; }
     if (name && !strcmp(name, "profile")) { vfr::g_opt_profile = value; return VFR_OK; }
     if (name && !strcmp(name, "score_fast")) { vfr::g_opt_score_fast = value; return VFR_OK; }
+    if (name && !strcmp(name, "score_split")) { vfr::g_opt_score_split = value; return VFR_OK; }
     return vfr::fail(VFR_EINVAL, "vfr_set_option: unknown option '%s'", name ? name : "(null)");
 }
 int vfr_get_option(const char *name)
@@ -92,6 +95,7 @@ int vfr_get_option(const char *name)
     if (name && !strcmp(name, "gemm")) return vfr::g_opt_gemm;
     if (name && !strcmp(name, "profile")) return vfr::g_opt_profile;
     if (name && !strcmp(name, "score_fast")) return vfr::g_opt_score_fast;
+    if (name && !strcmp(name, "score_split")) return vfr::g_opt_score_split;
     return vfr::fail(VFR_EINVAL, "vfr_get_option: unknown option '%s'", name ? name : "(null)");
 }
 
@@ -102,7 +106,7 @@ const char *vfr_profile_site_name(int site)
     static const char *names[vfr::SITE_COUNT] = {
         "none", "gemm_vis_seg", "gemm_vis_ctx", "vis_hidden", "gemm_vis_out", "embed", "gemm_lstm_in", "gemm_lstm_rec",
         "lstm_pointwise", "gemm_lang_fc", "score_fused", "topk_merge", "score_dense", "score_own", "pool", "linear",
-        "conv3x3", "pool2d", "normalize"};
+        "conv3x3", "pool2d", "normalize", "score_rank", "score_prepass", "repack"};
     return site >= 0 && site < vfr::SITE_COUNT ? names[site] : "?";
 }
 

@@ -18,6 +18,7 @@ inline hipStream_t as_stream(vfr_stream_t s) { return reinterpret_cast<hipStream
 // option switches (vfr_set_option)
 int opt_gemm();
 int opt_score_fast();
+int opt_score_split();
 
 // ---- launch-site profiler (vfr_set_option("profile", 1)): HIP events recorded on the launch stream
 // around every instrumented launch; vfr_profile_read() turns them into per-site totals after a sync.
@@ -26,7 +27,7 @@ enum Site : int {
     SITE_GEMM_VIS_SEG, SITE_GEMM_VIS_CTX, SITE_VIS_HIDDEN, SITE_GEMM_VIS_OUT,
     SITE_EMBED, SITE_GEMM_LSTM_IN, SITE_GEMM_LSTM_REC, SITE_LSTM_POINTWISE, SITE_GEMM_LANG_FC,
     SITE_SCORE_FUSED, SITE_TOPK_MERGE, SITE_SCORE_DENSE, SITE_SCORE_OWN, SITE_POOL, SITE_LINEAR,
-    SITE_CONV, SITE_POOL2D, SITE_NORMALIZE,
+    SITE_CONV, SITE_POOL2D, SITE_NORMALIZE, SITE_SCORE_RANK, SITE_SCORE_PREPASS, SITE_REPACK,
     SITE_COUNT
 };
 bool profiling();
@@ -71,5 +72,10 @@ struct GemmArgs {
     int site;                          // profiler site (SITE_NONE = not instrumented)
 };
 int gemm_nt(const GemmArgs &g, hipStream_t st);
+// two GEMMs of identical shape as ONE grid (blockIdx.z picks the problem): fills the chip when one alone leaves a
+// partial last round (the forward and reverse LSTM directions)
+int gemm_nt_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st);
+// copy a [rows, cols] block out of a wider row-major matrix into a dense, 16-byte aligned buffer
+int repack_rows(const float *src, int64_t ld_src, int rows, int cols, float *dst, hipStream_t st);
 
 }  // namespace vfr

@@ -38,11 +38,11 @@ __global__ __launch_bounds__(256) void visual_hidden_kernel(float *__restrict__ 
 
 extern "C" {
 
-size_t vfr_visual_mlp_workspace_bytes(int total_clips, int Nv, int hid)
+size_t vfr_visual_mlp_workspace_bytes(int total_clips, int Nv, int F, int hid)
 {
-    if (total_clips < 0 || Nv < 0 || hid < 0) return 0;
+    if (total_clips < 0 || Nv < 0 || hid < 0 || F < 0) return 0;
     return vfr::align_up((size_t)total_clips * hid * sizeof(float), 256) +
-           vfr::align_up((size_t)Nv * hid * sizeof(float), 256);
+           vfr::align_up((size_t)Nv * hid * sizeof(float), 256) + 2 * vfr::align_up((size_t)hid * F * sizeof(float), 256);
 }
 
 int vfr_visual_mlp_f32(const float *seg, const float *ctx, const int32_t *clip_offsets, int Nv, int total_clips,
@@ -53,19 +53,27 @@ int vfr_visual_mlp_f32(const float *seg, const float *ctx, const int32_t *clip_o
                     hid > 0 && D > 0,
                 VFR_EINVAL, "vfr_visual_mlp_f32: bad argument");
     if (total_clips == 0) return VFR_OK;
-    VFR_REQUIRE(workspace && workspace_bytes >= vfr_visual_mlp_workspace_bytes(total_clips, Nv, hid), VFR_EWORKSPACE,
+    VFR_REQUIRE(workspace && workspace_bytes >= vfr_visual_mlp_workspace_bytes(total_clips, Nv, F, hid), VFR_EWORKSPACE,
                 "vfr_visual_mlp_f32: workspace %zu < %zu bytes", workspace_bytes,
-                vfr_visual_mlp_workspace_bytes(total_clips, Nv, hid));
+                vfr_visual_mlp_workspace_bytes(total_clips, Nv, F, hid));
     hipStream_t st = vfr::as_stream(stream);
     float *S = static_cast<float *>(workspace);
     float *Cx = reinterpret_cast<float *>(static_cast<char *>(workspace) +
                                           vfr::align_up((size_t)total_clips * hid * sizeof(float), 256));
     const int ldw = 2 * F + 2;
+    // W1's rows are 2F+2 floats, so neither half starts 16-byte aligned: copy [W1_seg | W1_ctx] into dense
+    // aligned buffers (2 * hid * F floats, ~16 MB) so the GEMM stages them with 16-byte loads
+    char *wsb = static_cast<char *>(workspace);
+    float *Wseg = reinterpret_cast<float *>(wsb + vfr::align_up((size_t)total_clips * hid * sizeof(float), 256) +
+                                            vfr::align_up((size_t)Nv * hid * sizeof(float), 256));
+    float *Wctx = reinterpret_cast<float *>(reinterpret_cast<char *>(Wseg) + vfr::align_up((size_t)hid * F * sizeof(float), 256));
+    if (int rc = vfr::repack_rows(W1, ldw, hid, F, Wseg, st)) return rc;
+    if (int rc = vfr::repack_rows(W1 + F, ldw, hid, F, Wctx, st)) return rc;
     vfr::GemmArgs g{};
-    g.A = seg; g.lda = F; g.W = W1; g.ldw = ldw; g.out = S; g.ldo = hid; g.M = total_clips; g.N = hid; g.K = F;
+    g.A = seg; g.lda = F; g.W = Wseg; g.ldw = F; g.out = S; g.ldo = hid; g.M = total_clips; g.N = hid; g.K = F;
     g.site = vfr::SITE_GEMM_VIS_SEG;
     if (int rc = vfr::gemm_nt(g, st)) return rc;
-    g.A = ctx; g.W = W1 + F; g.out = Cx; g.M = Nv; g.site = vfr::SITE_GEMM_VIS_CTX;
+    g.A = ctx; g.W = Wctx; g.out = Cx; g.M = Nv; g.site = vfr::SITE_GEMM_VIS_CTX;
     if (int rc = vfr::gemm_nt(g, st)) return rc;
     {
     vfr::ProfScope prof(vfr::SITE_VIS_HIDDEN, st);
