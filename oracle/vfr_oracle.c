@@ -496,9 +496,11 @@ VFO_EXPORT void vfo_frames_normalize(const uint8_t *thwc, int T, int H, int W, f
 
 /* ------------------------------------------------------------------------------------------ */
 /* a2  VGG19 "E" feature stack up to fc7 (get_rgb_features.py:122-126; torchvision vgg19,       */
-/* version unpinned, absent here: arithmetic restated from the public configuration).           */
-/*   conv3x3 pad 1:  chain over k = (cin*3 + ky)*3 + kx ascending (weight layout [Cout,Cin,3,3] */
-/*   flattened), zero padding contributes fmaf(0,w,acc) = acc; + bias; ReLU.                    */
+/* version unpinned, absent here: arithmetic restated from the public configuration and pinned  */
+/* against torch.nn.functional in tests/test_oracle_vgg_torch.py).                              */
+/*   conv3x3 pad 1:  one chain per output over k = (ky*3 + kx)*Cin + ci ascending -- tap-major, */
+/*   channel-minor, the order an NHWC implicit GEMM consumes; zero padding contributes           */
+/*   fmaf(0,w,acc) = acc; + bias; ReLU.  Weights keep the reference layout [Cout,Cin,3,3].      */
 /* ------------------------------------------------------------------------------------------ */
 VFO_EXPORT void vfo_conv3x3_relu(const float *x, int B, int Cin, int H, int W, const float *w, const float *b,
                                  int Cout, float *y)
@@ -507,9 +509,9 @@ VFO_EXPORT void vfo_conv3x3_relu(const float *x, int B, int Cin, int H, int W, c
     for (int n = 0; n < B; ++n)
         for (int co = 0; co < Cout; ++co) {
             float *acc = (float *)calloc((size_t)H * W, sizeof(float));
-            for (int ci = 0; ci < Cin; ++ci)
-                for (int ky = 0; ky < 3; ++ky)
-                    for (int kx = 0; kx < 3; ++kx) {
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx)
+                    for (int ci = 0; ci < Cin; ++ci) {
                         float wv = w[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx];
                         const float *xp = x + ((size_t)n * Cin + ci) * H * W;
                         for (int oy = 0; oy < H; ++oy) {

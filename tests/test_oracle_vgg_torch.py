@@ -1,0 +1,39 @@
+"""a1/a2 pin: torchvision is absent and its weights are a network fetch, so the oracle's VGG-"E"
+restatement is pinned against the same composition written with torch.nn.functional on CPU (the ops torchvision's
+vgg19 is made of: Conv2d 3x3 pad 1, ReLU, MaxPool2d 2x2, AdaptiveAvgPool2d(7), Linear) at reduced width.
+Tolerance 1e-4 relative to the activation scale; the HIP kernels are then checked bit-for-bit against the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from vfr_amd import synth
+
+CFG = [8, 8, "M", 16, 16, "M", 24, 24, 24, 24, "M", 32, 32, 32, 32, "M", 32, 32, 32, 32, "M"]
+
+
+@pytest.mark.parametrize("hw", [(32, 32), (64, 48), (224, 224)])
+def test_oracle_vgg_matches_torch_functional(oracle, hw):
+    H, W = hw
+    T = 2 if H == 224 else 3
+    frames = synth.frames_u8(T, H, W, seed=4)
+    cw, cb, fc6, fc7 = synth.vgg_weights(CFG, hw, 48, seed=4)
+    got = oracle.vgg_fc7(frames, cw, cb, fc6, fc7, CFG)
+
+    mean = torch.tensor([0.485, 0.456, 0.406])
+    std = torch.tensor([0.229, 0.224, 0.225])
+    x = torch.from_numpy(frames).transpose(3, 1).transpose(2, 3).float().div(255)      # get_rgb_features.py:64-69
+    x = x.sub(mean[None, :, None, None]).div(std[None, :, None, None])
+    assert np.array_equal(x.numpy(), oracle.frames_normalize(frames))                  # a1 is exact
+    i = 0
+    for item in CFG:
+        if item == "M":
+            x = F.max_pool2d(x, 2, 2)
+        else:
+            x = F.relu(F.conv2d(x, torch.from_numpy(cw[i]), torch.from_numpy(cb[i]), padding=1))
+            i += 1
+    x = F.adaptive_avg_pool2d(x, (7, 7)).flatten(1)
+    x = F.relu(F.linear(x, torch.from_numpy(fc6[0]), torch.from_numpy(fc6[1])))
+    want = F.relu(F.linear(x, torch.from_numpy(fc7[0]), torch.from_numpy(fc7[1]))).numpy()
+    scale = max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * scale)

@@ -107,7 +107,7 @@ __device__ __forceinline__ float4 load4_guard(const float *__restrict__ P, int64
 
 struct GemmPair { GemmArgs p[2]; };
 
-template <bool VEC>
+template <bool VEC, bool CONV>
 __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
     // double-buffered tiles: [2][A 128x36 | W 128x36] floats = 73,728 B -> two workgroups per CU
@@ -139,7 +139,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
         const int64_t ma = m0 + row < g.M ? m0 + row : g.M - 1;
         const int64_t nw = (int64_t)n0 + row < g.N ? (int64_t)n0 + row : g.N - 1;
-        arow[i] = g.A + ma * g.lda + kk;
+        arow[i] = CONV ? g.A : g.A + ma * g.lda + kk;
         wrow[i] = g.W + nw * g.ldw + kk;
     }
     auto gload_full = [&](int k0) {
@@ -162,7 +162,41 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             rw[i] = load4_guard<false>(g.W, g.ldw, (int64_t)n0 + row, g.N, k0 + kk, g.K);
         }
     };
-    const int nk_full = g.K / MBK;
+    // ---- implicit-GEMM conv loader: per staged row the output pixel is fixed, per K-tile the thread's 4 consecutive
+    // k's share one tap (conv_cin % 4 == 0); loads are unconditional from a clamped address, then zero-selected.
+    int cn[4], coy[4], cox[4];
+    bool crow_ok[4];
+    if (CONV) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i, row = f >> 3;
+            const int64_t p = m0 + row;
+            crow_ok[i] = p < g.M;
+            const int64_t pc = crow_ok[i] ? p : 0;
+            const int hw = g.conv_h * g.conv_w;
+            cn[i] = (int)(pc / hw);
+            const int rem = (int)(pc - (int64_t)cn[i] * hw);
+            coy[i] = rem / g.conv_w;
+            cox[i] = rem - coy[i] * g.conv_w;
+        }
+    }
+    auto gload_conv = [&](int k0) {
+        const int kk = (tid & 7) * 4, k = k0 + kk;
+        const bool kok = k < g.K;
+        const int kc = kok ? k : 0;
+        const int tap = kc / g.conv_cin, ci = kc - tap * g.conv_cin, ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = coy[i] + ky - 1, ix = cox[i] + kx - 1;
+            const bool ok = kok && crow_ok[i] && iy >= 0 && iy < g.conv_h && ix >= 0 && ix < g.conv_w;
+            const int64_t off = ok ? (((int64_t)cn[i] * g.conv_h + iy) * g.conv_w + ix) * g.conv_cin + ci : 0;
+            const float4 v = *reinterpret_cast<const float4 *>(g.A + off);
+            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 wv = *reinterpret_cast<const float4 *>(wrow[i] - kk + kc);     // row clamped, k clamped
+            rw[i] = kok ? wv : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    const int nk_full = CONV ? (g.K + MBK - 1) / MBK : g.K / MBK;     // conv: every tile through the select loader
     auto swrite = [&](int b) {
         float *As = lds + b * (MBM + MBN) * MLD, *Ws = As + MBM * MLD;
 #pragma unroll
@@ -202,11 +236,12 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // main loop over the FULL K-tiles, branch-free: iteration kt prefetches tile min(kt+1, last) (the final
     // iteration re-reads its own tile, which is harmless) so no control-flow join sits between the loads and the
     // MFMA block -- a join there makes the compiler drain vmcnt(0) before the first MFMA.
-    if (nk_full > 0) { gload_full(0); swrite(0); }
+    auto gload_main = [&](int k0) { if (CONV) gload_conv(k0); else gload_full(k0); };
+    if (nk_full > 0) { gload_main(0); swrite(0); }
     __syncthreads();
     for (int kt = 0; kt < nk_full; ++kt) {
         const int nxt = kt + 1 < nk_full ? kt + 1 : nk_full - 1;
-        gload_full(nxt * MBK);
+        gload_main(nxt * MBK);
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
         compute(kt & 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -215,7 +250,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         swrite((kt + 1) & 1);
         __syncthreads();
     }
-    if (g.K % MBK) {                       // partial last tile: guarded loads, zero padded (fma(0,0,acc) == acc)
+    if (!CONV && (g.K % MBK)) {            // partial last tile: guarded loads, zero padded (fma(0,0,acc) == acc)
         gload_tail(nk_full * MBK);
         swrite(nk_full & 1);
         __syncthreads();
@@ -244,10 +279,12 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_nt_mfma(GemmArgs g) { gemm_nt_mfma_body<VEC>(g); }
+__global__ __launch_bounds__(256, 2) void gemm_nt_mfma(GemmArgs g) { gemm_nt_mfma_body<VEC, false>(g); }
 
 template <bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp) { gemm_nt_mfma_body<VEC>(gp.p[blockIdx.z]); }
+__global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp) { gemm_nt_mfma_body<VEC, false>(gp.p[blockIdx.z]); }
+
+__global__ __launch_bounds__(256, 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true>(g); }
 
 __global__ __launch_bounds__(256) void repack_rows_kernel(const float *__restrict__ src, int64_t ld_src, int rows, int cols,
                                                           float *__restrict__ dst)
@@ -297,14 +334,22 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
     VFR_REQUIRE(!(g.epi & (EPI_BIAS | EPI_BIAS2)) || g.bias, VFR_EINVAL, "gemm_nt: bias flag without bias");
     VFR_REQUIRE(!(g.epi & EPI_BIAS2) || g.bias2, VFR_EINVAL, "gemm_nt: bias2 flag without bias2");
     ProfScope prof(g.site, st);
+    dim3 grid((unsigned)cdiv(g.M, MBM), (unsigned)cdiv(g.N, MBN));
+    if (g.conv_cin > 0) {                      // implicit-GEMM convolution: MFMA kernel only
+        VFR_REQUIRE((g.conv_cin & 3) == 0 && g.K == 9 * g.conv_cin && (g.ldw & 3) == 0 &&
+                        ((((uintptr_t)g.A) | ((uintptr_t)g.W)) & 15) == 0,
+                    VFR_EINVAL, "gemm_nt(conv): needs Cin %% 4 == 0, K = 9*Cin and 16-byte aligned operands");
+        hipLaunchKernelGGL(conv3x3_nhwc_mfma, grid, dim3(256), 0, st, g);
+        VFR_CHECK_LAUNCH("conv3x3_nhwc_mfma");
+        return VFR_OK;
+    }
     if (opt_gemm() == 0) {
-        dim3 grid((unsigned)cdiv(g.M, VBM), (unsigned)cdiv(g.N, VBN));
-        hipLaunchKernelGGL(gemm_nt_valu, grid, dim3(256), 0, st, g);
+        dim3 vgrid((unsigned)cdiv(g.M, VBM), (unsigned)cdiv(g.N, VBN));
+        hipLaunchKernelGGL(gemm_nt_valu, vgrid, dim3(256), 0, st, g);
         VFR_CHECK_LAUNCH("gemm_nt_valu");
         return VFR_OK;
     }
     const bool vec = gemm_vec_ok(g);
-    dim3 grid((unsigned)cdiv(g.M, MBM), (unsigned)cdiv(g.N, MBN));
     if (vec) hipLaunchKernelGGL(gemm_nt_mfma<true>, grid, dim3(256), 0, st, g);
     else     hipLaunchKernelGGL(gemm_nt_mfma<false>, grid, dim3(256), 0, st, g);
     VFR_CHECK_LAUNCH("gemm_nt_mfma");

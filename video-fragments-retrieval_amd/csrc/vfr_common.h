@@ -70,6 +70,10 @@ struct GemmArgs {
     int64_t M; int N; int K;
     int epi;
     int site;                          // profiler site (SITE_NONE = not instrumented)
+    // implicit-GEMM 3x3 convolution (conv_cin > 0): A is an NHWC activation [B, conv_h, conv_w, conv_cin]; row m is the
+    // output pixel (n, oy, ox), column k = (ky*3 + kx)*conv_cin + ci reads x[n][oy+ky-1][ox+kx-1][ci] (0 outside).
+    // M = B*conv_h*conv_w, K = 9*conv_cin (conv_cin % 4 == 0), out [M, N] is the NHWC output.
+    int conv_h, conv_w, conv_cin;
 };
 int gemm_nt(const GemmArgs &g, hipStream_t st);
 // two GEMMs of identical shape as ONE grid (blockIdx.z picks the problem): fills the chip when one alone leaves a

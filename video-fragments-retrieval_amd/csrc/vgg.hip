@@ -3,8 +3,8 @@
 //
 // Canonical arithmetic (matches oracle/vfr_oracle.c):
 //   normalise : ((u8 / 255) - mean[c]) / std[c]
-//   conv3x3   : one fma chain per output over k = (cin*3 + ky)*3 + kx ascending (the [Cout,Cin,3,3]
-//               weight layout), zero padding contributes fma(0, w, acc) = acc; + bias; ReLU
+//   conv3x3   : one fma chain per output over k = (ky*3 + kx)*Cin + ci ascending (tap-major, channel-minor:
+//               what the NHWC implicit GEMM consumes), zero padding contributes fma(0, w, acc) = acc; + bias; ReLU
 //   maxpool   : max of the 2x2 window;  adaptive avgpool 7x7: row-major window sum / count
 //   fc6 / fc7 : chain GEMM + bias + ReLU (gemm.hip)
 #include "vfr_common.h"
@@ -45,16 +45,15 @@ __global__ __launch_bounds__(256) void conv3x3_relu_kernel(const float *__restri
     float acc[CO_T];
 #pragma unroll
     for (int j = 0; j < CO_T; ++j) acc[j] = 0.0f;
-    for (int ci = 0; ci < Cin; ++ci) {
-        const float *xp = x + ((int64_t)n * Cin + ci) * H * W;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy + ky - 1;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy + ky - 1;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox + kx - 1;
-                const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const float xv = in ? xp[(int64_t)iy * W + ix] : 0.0f;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox + kx - 1;
+            const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            for (int ci = 0; ci < Cin; ++ci) {            // canonical chain order: (ky, kx, ci) ascending
+                const float xv = in ? x[(((int64_t)n * Cin + ci) * H + iy) * W + ix] : 0.0f;
 #pragma unroll
                 for (int j = 0; j < CO_T; ++j) {
                     const int co = co0 + j;
@@ -100,6 +99,74 @@ __global__ __launch_bounds__(256) void adaptive_avgpool7_kernel(const float *__r
     y[i] = acc / (float)((y1 - y0) * (x1 - x0));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// NHWC pipeline of the whole stack (vfr_vgg_fc7_f32): the input frames are THWC already, every conv is an
+// implicit GEMM on the MFMA chain kernel (gemm.hip, conv loader), activations stay channel-minor so the
+// A-operand gathers are 16-byte vectors.  The 3 input channels are padded to 4 (zero channel x zero weights:
+// fma(0, 0, acc) = acc, so the chain is unchanged).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frames_normalize_nhwc4_kernel(const uint8_t *__restrict__ in, int64_t pixels,
+                                                                     float *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pixels) return;
+    float4 o;
+    float v;
+    v = (float)in[i * 3 + 0]; v = v / 255.0f; v = v - c_mean[0]; o.x = v / c_std[0];
+    v = (float)in[i * 3 + 1]; v = v / 255.0f; v = v - c_mean[1]; o.y = v / c_std[1];
+    v = (float)in[i * 3 + 2]; v = v / 255.0f; v = v - c_mean[2]; o.z = v / c_std[2];
+    o.w = 0.0f;
+    reinterpret_cast<float4 *>(out)[i] = o;
+}
+
+// w [Cout, Cin, 3, 3] -> wr [Cout, 9 * Cinp], k = (ky*3 + kx) * Cinp + ci, zero for ci >= Cin
+__global__ __launch_bounds__(256) void conv_weight_repack_kernel(const float *__restrict__ w, int Cout, int Cin, int Cinp,
+                                                                 float *__restrict__ wr)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = 9 * Cinp;
+    if (i >= (int64_t)Cout * K) return;
+    const int co = (int)(i / K), k = (int)(i - (int64_t)co * K), tap = k / Cinp, ci = k - tap * Cinp;
+    wr[i] = ci < Cin ? w[((int64_t)co * Cin + ci) * 9 + tap] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void maxpool2_nhwc_kernel(const float *__restrict__ x, int64_t B, int H, int W, int C,
+                                                            float *__restrict__ y)
+{
+    const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Ho * Wo * C4) return;
+    const int c4 = (int)(i % C4);
+    int64_t r = i / C4;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int64_t n = r / Ho;
+    const float4 *p = reinterpret_cast<const float4 *>(x) + (((n * H + 2 * oy) * W + 2 * ox) * (int64_t)C4 + c4);
+    const float4 a = p[0], b = p[C4], c = p[(int64_t)W * C4], d = p[(int64_t)W * C4 + C4];
+    float4 o;
+    o.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
+    o.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+    o.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z));
+    o.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+    reinterpret_cast<float4 *>(y)[i] = o;
+}
+
+// NHWC [B,H,W,C] -> [B, C*49] in torch's flatten order (channel-major), windows as AdaptiveAvgPool2d((7,7))
+__global__ __launch_bounds__(256) void adaptive_avgpool7_nhwc_kernel(const float *__restrict__ x, int64_t B, int H, int W,
+                                                                     int C, float *__restrict__ y)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C * 49) return;
+    const int ox = (int)(i % 7), oy = (int)((i / 7) % 7), c = (int)((i / 49) % C);
+    const int64_t n = i / (49 * (int64_t)C);
+    const int y0 = (oy * H) / 7, y1 = ((oy + 1) * H + 6) / 7, x0 = (ox * W) / 7, x1 = ((ox + 1) * W + 6) / 7;
+    float acc = 0.0f;
+    for (int iy = y0; iy < y1; ++iy)
+        for (int ix = x0; ix < x1; ++ix) acc = acc + x[((n * H + iy) * W + ix) * (int64_t)C + c];
+    y[i] = acc / (float)((y1 - y0) * (x1 - x0));
+}
+
 static int run_conv(const float *x, int B, int Cin, int H, int W, const float *w, const float *b, int Cout, float *y,
                     hipStream_t st)
 {
@@ -126,15 +193,22 @@ static int run_avgpool(const float *x, int64_t planes, int H, int W, float *y, h
 
 constexpr int VGG_FRAME_CHUNK = 32;   // frames per pass through the conv stack (bounds the workspace)
 
-struct VggPlan { size_t act_elems; int c_last, h_last, w_last; bool ok; };
+struct VggPlan { size_t act_elems, wr_elems; int c_last, h_last, w_last; bool ok; };
 static VggPlan plan_vgg(int chunk, int H, int W, const int *cfg, int ncfg)
 {
-    VggPlan p{0, 3, H, W, true};
-    size_t cur = (size_t)chunk * 3 * H * W;
+    VggPlan p{0, 0, 4, H, W, true};                      // the 3 input channels travel padded to 4
+    size_t cur = (size_t)chunk * 4 * H * W;
     p.act_elems = cur;
+    int cin = 4;
     for (int i = 0; i < ncfg; ++i) {
-        if (cfg[i] > 0) p.c_last = cfg[i];
-        else { if (p.h_last < 2 || p.w_last < 2) p.ok = false; p.h_last /= 2; p.w_last /= 2; }
+        if (cfg[i] > 0) {
+            if (cfg[i] % 4) p.ok = false;                 // NHWC float4 path
+            p.wr_elems += align_up((size_t)cfg[i] * 9 * cin, 64);
+            cin = p.c_last = cfg[i];
+        } else {
+            if (p.h_last < 2 || p.w_last < 2) p.ok = false;
+            p.h_last /= 2; p.w_last /= 2;
+        }
         cur = (size_t)chunk * p.c_last * p.h_last * p.w_last;
         if (cur > p.act_elems) p.act_elems = cur;
     }
@@ -187,7 +261,8 @@ size_t vfr_vgg_fc7_workspace_bytes(int T, int H, int W, const int *cfg_host, int
     size_t act = vfr::align_up(p.act_elems * sizeof(float), 256);
     size_t pooled = vfr::align_up((size_t)T * p.c_last * 49 * sizeof(float), 256);
     size_t h6 = vfr::align_up((size_t)T * fc_dim * sizeof(float), 256);
-    return 2 * act + pooled + h6;
+    size_t wr = vfr::align_up(p.wr_elems * sizeof(float), 256);
+    return 2 * act + pooled + h6 + wr;
 }
 
 int vfr_vgg_fc7_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *cfg_host, int ncfg,
@@ -201,36 +276,80 @@ int vfr_vgg_fc7_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *
     if (T == 0) return VFR_OK;
     const int chunk = T < vfr::VGG_FRAME_CHUNK ? T : vfr::VGG_FRAME_CHUNK;
     vfr::VggPlan p = vfr::plan_vgg(chunk, H, W, cfg_host, ncfg);
-    VFR_REQUIRE(p.ok, VFR_EUNSUPPORTED, "vfr_vgg_fc7_f32: %dx%d frames too small for %d pooling stages", H, W, ncfg);
+    VFR_REQUIRE(p.ok, VFR_EUNSUPPORTED,
+                "vfr_vgg_fc7_f32: needs conv widths that are multiples of 4 and %dx%d frames large enough for the pooling stages",
+                H, W);
     VFR_REQUIRE(workspace && workspace_bytes >= vfr_vgg_fc7_workspace_bytes(T, H, W, cfg_host, ncfg, fc_dim),
                 VFR_EWORKSPACE, "vfr_vgg_fc7_f32: workspace %zu < %zu bytes", workspace_bytes,
                 vfr_vgg_fc7_workspace_bytes(T, H, W, cfg_host, ncfg, fc_dim));
     hipStream_t st = vfr::as_stream(stream);
     char *base = static_cast<char *>(workspace);
     const size_t act = vfr::align_up(p.act_elems * sizeof(float), 256);
+    const size_t pooled_b = vfr::align_up((size_t)T * p.c_last * 49 * sizeof(float), 256);
+    const size_t h6_b = vfr::align_up((size_t)T * fc_dim * sizeof(float), 256);
     float *bufA = reinterpret_cast<float *>(base), *bufB = reinterpret_cast<float *>(base + act);
     float *pooled = reinterpret_cast<float *>(base + 2 * act);
-    float *h6 = reinterpret_cast<float *>(base + 2 * act + vfr::align_up((size_t)T * p.c_last * 49 * sizeof(float), 256));
+    float *h6 = reinterpret_cast<float *>(base + 2 * act + pooled_b);
+    float *wr_base = reinterpret_cast<float *>(base + 2 * act + pooled_b + h6_b);
     const int K6 = p.c_last * 49;
+
+    // repack every conv weight once per call: [Cout,Cin,3,3] -> [Cout, 9*Cinp] tap-major (the chain order)
+    {
+        vfr::ProfScope prof(vfr::SITE_REPACK, st);
+        float *wr = wr_base;
+        int cin = 3, conv = 0;
+        for (int i = 0; i < ncfg; ++i) {
+            if (cfg_host[i] <= 0) continue;
+            const int cinp = cin < 4 ? 4 : cin, cout = cfg_host[i];
+            const int64_t n = (int64_t)cout * 9 * cinp;
+            hipLaunchKernelGGL(vfr::conv_weight_repack_kernel, dim3((unsigned)vfr::cdiv(n, 256)), dim3(256), 0, st,
+                               conv_w_host[conv], cout, cin, cinp, wr);
+            wr += vfr::align_up((size_t)n, 64);
+            cin = cout;
+            ++conv;
+        }
+    }
+    VFR_CHECK_LAUNCH("conv_weight_repack_kernel");
 
     for (int t0 = 0; t0 < T; t0 += chunk) {
         const int bt = (T - t0) < chunk ? (T - t0) : chunk;
-        if (int rc = vfr_frames_normalize_f32(frames_thwc + (size_t)t0 * H * W * 3, bt, H, W, bufA, stream)) return rc;
+        {
+            vfr::ProfScope prof(vfr::SITE_NORMALIZE, st);
+            const int64_t pixels = (int64_t)bt * H * W;
+            hipLaunchKernelGGL(vfr::frames_normalize_nhwc4_kernel, dim3((unsigned)vfr::cdiv(pixels, 256)), dim3(256), 0, st,
+                               frames_thwc + (size_t)t0 * H * W * 3, pixels, bufA);
+        }
+        VFR_CHECK_LAUNCH("frames_normalize_nhwc4_kernel");
         float *cur = bufA, *nxt = bufB;
-        int c = 3, h = H, w = W, conv = 0;
+        const float *wr = wr_base;
+        int c = 4, h = H, w = W, conv = 0;
         for (int i = 0; i < ncfg; ++i) {
             if (cfg_host[i] > 0) {
-                if (int rc = vfr::run_conv(cur, bt, c, h, w, conv_w_host[conv], conv_b_host[conv], cfg_host[i], nxt, st))
-                    return rc;
-                c = cfg_host[i];
+                const int cout = cfg_host[i];
+                vfr::GemmArgs g{};
+                g.A = cur; g.W = wr; g.ldw = 9 * c; g.out = nxt; g.ldo = cout; g.M = (int64_t)bt * h * w; g.N = cout;
+                g.K = 9 * c; g.bias = conv_b_host[conv]; g.epi = vfr::EPI_BIAS | vfr::EPI_RELU; g.site = vfr::SITE_CONV;
+                g.conv_h = h; g.conv_w = w; g.conv_cin = c;
+                if (int rc = vfr::gemm_nt(g, st)) return rc;
+                wr += vfr::align_up((size_t)cout * 9 * c, 64);
+                c = cout;
                 ++conv;
             } else {
-                if (int rc = vfr::run_maxpool(cur, (int64_t)bt * c, h, w, nxt, st)) return rc;
+                vfr::ProfScope prof(vfr::SITE_POOL2D, st);
+                const int64_t n = (int64_t)bt * (h / 2) * (w / 2) * (c / 4);
+                hipLaunchKernelGGL(vfr::maxpool2_nhwc_kernel, dim3((unsigned)vfr::cdiv(n, 256)), dim3(256), 0, st, cur,
+                                   (int64_t)bt, h, w, c, nxt);
                 h /= 2; w /= 2;
             }
             float *tmp = cur; cur = nxt; nxt = tmp;
         }
-        if (int rc = vfr::run_avgpool(cur, (int64_t)bt * c, h, w, pooled + (size_t)t0 * K6, st)) return rc;
+        VFR_CHECK_LAUNCH("vgg conv stack");
+        {
+            vfr::ProfScope prof(vfr::SITE_POOL2D, st);
+            hipLaunchKernelGGL(vfr::adaptive_avgpool7_nhwc_kernel, dim3((unsigned)vfr::cdiv((int64_t)bt * c * 49, 256)),
+                               dim3(256), 0, st, cur, (int64_t)bt, h, w, c, pooled + (size_t)t0 * K6);
+        }
+        VFR_CHECK_LAUNCH("adaptive_avgpool7_nhwc_kernel");
     }
     if (int rc = vfr_linear_f32(pooled, T, K6, fc6_w, fc6_b, fc_dim, 1, h6, stream)) return rc;
     return vfr_linear_f32(h6, T, fc_dim, fc7_w, fc7_b, fc_dim, 1, out, stream);
