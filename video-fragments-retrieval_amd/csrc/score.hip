@@ -413,7 +413,7 @@ template <> struct FastCfg<6> { static constexpr int NC = 3; };
 __device__ __forceinline__ unsigned excl_bound(float s) { return s < 0.0f ? 0u : __float_as_uint(s) + 1u; }
 
 template <int NT, int KPL, int NR, bool TOPK, bool EXACT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((NT > 6 && NR > 0 && TOPK) ? 1 : 2, 8)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ Vp, const int32_t *__restrict__ clip_off,
                        const int64_t *__restrict__ mom_off, const float *__restrict__ rank_dist,
                        const int64_t *__restrict__ rank_idx, ScoreArgs a)
@@ -422,11 +422,15 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
     constexpr int CAP = KPL * 64, NC = FastCfg<NT>::NC, ROW4 = FAST_D / 4, G4 = NC * ROW4;   // float4 per group
     constexpr int NLD = (G4 + 63) / 64;                                                       // loads per lane
     constexpr int NRR = NR > 0 ? NR : 1;
+    // the one combination that would not fit 256 registers (n = 21, top-k AND rank keys) keeps its rank bounds in LDS
+    // ([r][L][lane] column, 2 ds_read per span length) -- 19.4 KB per wave, so 8 waves/CU still fit in 160 KB
+    constexpr bool LOX_LDS = NT > 6 && NR > 0 && TOPK;
     const int lane = threadIdx.x;
     const int task = blockIdx.x;
     const int chunk = task / a.num_groups, group = task - chunk * a.num_groups;
     float *stage = smem;                              // [2][NC*100]  staged clip rows (double buffer)
     float *ds = smem + 2 * NC * FAST_D;               // [ceil(NT/NC)*NC][64] clip distances of the current video
+    unsigned *lox_lds = reinterpret_cast<unsigned *>(ds + ((NT + NC - 1) / NC) * NC * 64);   // [NR][NT][64] when LOX_LDS
 
     const int64_t qi = (int64_t)group * 64 + lane;
     const bool active = qi < a.Nq;
@@ -445,7 +449,7 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
 
     // threshold tables, statically indexed (registers): index L-1
     unsigned hix_t[TOPK ? NT : 1];                    // top-k filter: bits(sum) < hix_t  <=  score <= thr distance
-    unsigned lox[NRR][NT];                            // rank r: score <  key distance
+    unsigned lox[LOX_LDS ? 1 : NRR][LOX_LDS ? 1 : NT];   // rank r: score <  key distance (registers unless LOX_LDS)
     unsigned long long dl[NRR];                       // rank r: 2-bit (HIX - LOX) per L, packed
     bool wide = false;                                // some delta did not fit 2 bits: treat every video as a tie
 #pragma unroll
@@ -458,7 +462,7 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
             const unsigned hi = active ? excl_bound(sum_bound<false>(x, L)) : 0u;
             const unsigned d = hi - lo;
             wide = wide || d > 3u;
-            lox[r][L - 1] = lo;
+            if (LOX_LDS) lox_lds[(r * NT + (L - 1)) * 64 + lane] = lo; else lox[r][L - 1] = lo;
             dl[r] |= (unsigned long long)(d & 3u) << (2 * (L - 1));
         }
     }
@@ -560,9 +564,12 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
         bool tie = wide;
 #pragma unroll
         for (int L = 1; L <= NT; ++L) {
-            unsigned hx[NRR];
+            unsigned lx[NRR], hx[NRR];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) hx[r] = lox[r][L - 1] + ((unsigned)(dl[r] >> (2 * (L - 1))) & 3u);
+            for (int r = 0; r < NR; ++r) {
+                lx[r] = LOX_LDS ? lox_lds[(r * NT + (L - 1)) * 64 + lane] : lox[LOX_LDS ? 0 : r][LOX_LDS ? 0 : L - 1];
+                hx[r] = lx[r] + ((unsigned)(dl[r] >> (2 * (L - 1))) & 3u);
+            }
 #pragma unroll
             for (int s = 0; s + L <= NT; ++s) {
                 if (EXACT || s + L <= n) {                 // wave-uniform
@@ -580,7 +587,7 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
                     }
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
-                        const bool below = sb < lox[r][L - 1];
+                        const bool below = sb < lx[r];
                         nlt[r] += below ? 1 : 0;
                         tie = tie || ((sb < hx[r]) && !below);
                     }
@@ -850,9 +857,12 @@ static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st, int *cap_tr
         const int NT = NTsel;
         kpl = a.k + Msel <= 256 ? 4 : 8;                   // candidate columns hold k kept + one video's worth
         if (cap_transposed && a.k > 0) *cap_transposed = kpl * 64;
-        const bool exact = a.min_clips == NT;              // every video has exactly NT clips: no length guards
+        const bool lox_lds = NT > 6 && a.num_rank > 0 && a.k > 0 && !opt_score_split();
+        // every video has exactly NT clips: no length guards (the fused n=21 kernel keeps them: without the guards'
+        // scalar branches hipcc hoists the unrolled triangle's LDS reads and spills)
+        const bool exact = a.min_clips == NT && !lox_lds;
         const int NCg = NT == 6 ? 3 : 4, rows = (NT + NCg - 1) / NCg * NCg;
-        const size_t lds = ((size_t)2 * NCg * FAST_D + (size_t)rows * 64) * sizeof(float);
+        const size_t lds = ((size_t)2 * NCg * FAST_D + (size_t)rows * 64 + (lox_lds ? (size_t)a.num_rank * NT * 64 : 0)) * sizeof(float);
         dim3 grid((unsigned)tasks);
         if (NT == 6) { if (exact) launch_fast_nt<6, true>(a, kpl, grid, lds, st); else launch_fast_nt<6, false>(a, kpl, grid, lds, st); }
         else         { if (exact) launch_fast_nt<21, true>(a, kpl, grid, lds, st); else launch_fast_nt<21, false>(a, kpl, grid, lds, st); }

@@ -12,7 +12,7 @@ static thread_local char g_err[512] = "";
 static int g_opt_gemm = 1;
 static int g_opt_profile = 0;
 static int g_opt_score_fast = 1;
-static int g_opt_score_split = 1;
+static int g_opt_score_split = 0;
 
 struct ProfPair { int site; hipEvent_t a, b; };
 static std::vector<ProfPair> g_pairs;          // recorded, not yet read
