@@ -63,10 +63,11 @@ def site_work(site, cfg):
         "gemm_vis_ctx": 2.0 * Nv * hid * F,
         "gemm_vis_out": 2.0 * C * D * hid,
         "gemm_lang_fc": 2.0 * B * D * 2 * H,
-        # scoring launches (2nD contraction + n norms + 2M moment means per scoring); the sample
-        # pre-pass covers 256 videos, the top-k launch the rest, the rank launch everything
+        # scoring launches (2nD contraction + n norms + 2M moment means per scoring).  With top-k the
+        # first 256 videos are the threshold sample (pre-pass + a rank-only launch over them); the fused launch
+        # (top-k + rank keys, one distance pass) covers the rest.
         "score_fused": float(Nq) * max(Nv - 256, 0) * (2 * n * D + n + 2 * M),
-        "score_rank": float(Nq) * Nv * (2 * n * D + n + 2 * M),
+        "score_rank": float(Nq) * min(Nv, 256) * (2 * n * D + n + 2 * M),
         "score_prepass": float(Nq) * min(Nv, 256) * (2 * n * D + n + 2 * M),
     }
     return table.get(site)
@@ -202,8 +203,12 @@ def main():
     dom_ms_launch = dom_ms / sites[dom][1]
     fl = site_work(dom, cfg)
     achieved = fl / (dom_ms_launch * 1e-3) / 1e12 if fl else None
+    traffic = None                      # HBM bytes/launch of this kernel from the committed PMC passes (profiles/README.md)
+    tfile = ROOT / "profiles" / "traffic_latest.json"
+    if tfile.exists():
+        traffic = json.loads(tfile.read_text()).get(dom)
     roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": (achieved / FP32_PEAK_TFLOPS) if achieved else None, "traffic": None,
+                "frac": (achieved / FP32_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
                 "avg_launch_ms": dom_ms_launch, "launches_per_step": sites[dom][1] / args.steps,
                 "share_of_step": dom_ms / args.steps / ms_step}
     line = {
