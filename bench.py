@@ -57,8 +57,8 @@ def site_work(site, cfg):
     B, C, Nv, H, E, F, hid, D, n, Nq = (cfg[k] for k in ("Bq", "C", "Nv", "H", "E", "F", "hid", "D", "n", "Nq"))
     M = n * (n + 1) // 2
     table = {
-        "gemm_lstm_rec": 2.0 * 2 * B * 4 * H * H,             # forward + reverse launched as one grid
-        "gemm_lstm_in": 2.0 * 2 * B * cfg["T"] * 4 * H * E,
+        "gemm_lstm_rec": 2.0 * 2 * B * 4 * H * (E + H),       # fused step: [x_t | h] x [Wih | Whh]^T, both directions
+        "gemm_lstm_in": 2.0 * 2 * B * 4 * H * E,
         "gemm_vis_seg": 2.0 * C * hid * F,
         "gemm_vis_ctx": 2.0 * Nv * hid * F,
         "gemm_vis_out": 2.0 * C * D * hid,

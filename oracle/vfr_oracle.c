@@ -259,42 +259,50 @@ VFO_EXPORT void vfo_visual_mlp(const float *seg, const float *ctx, const int32_t
 /* ------------------------------------------------------------------------------------------ */
 /* a8  CALModel GloVe branch (model/models.py:61-66): Embedding -> [optional unit-norm x        */
 /* learnable length, :62-64] -> BiLSTM(H), h0=c0=0, ALL T steps incl. pads (Q6) -> Linear.      */
-/* torch.nn.LSTM gate order i,f,g,o.  Canonical order:                                          */
-/*   gin[t][j] = chain_{k<E} x_t[k]*Wih[j][k] + (bih[j] + bhh[j])                               */
-/*   gate[j]   = chain_{k<H} h[k]*Whh[j][k]  starting from acc = gin[t][j]                      */
+/* torch.nn.LSTM gate order i,f,g,o.  Canonical order (one chain over the concatenated          */
+/* [x_t | h] operand, the form the fused MFMA step kernel computes):                            */
+/*   acc     = chain_{k<E} x_t[k]*Wih[j][k]   (from 0)   then continues                          */
+/*             chain_{k<H} h[k]*Whh[j][k]                                                       */
+/*   gate[j] = acc + (bih[j] + bhh[j])                                                          */
 /*   c' = fmaf(f, c, i*g);  h' = o * tanh(c')                                                   */
-/*   out[d]    = chain_{k<2H} [h_fwd|h_bwd][k]*Wfc[d][k] + bfc[d]                               */
+/*   out[d]  = chain_{k<2H} [h_fwd|h_bwd][k]*Wfc[d][k] + bfc[d]                                 */
 /* ------------------------------------------------------------------------------------------ */
 static void lstm_dir(const float *X /*[B,T,E]*/, long B, int T, int E, int H, const float *Wih, const float *Whh,
                      const float *bih, const float *bhh, int reverse, float *hout /*[B, ld]*/, long ld)
 {
-    int G = 4 * H;
-    float *Wih_t = transpose_nk(Wih, G, E);
-    float *Whh_t = transpose_nk(Whh, G, H);
-    float *gin = (float *)malloc((size_t)B * T * G * sizeof(float));
-    chain_gemm(X, E, B * T, E, Wih_t, G, NULL, 0, gin, G);
-    for (long r = 0; r < B * T; ++r)
-        for (int j = 0; j < G; ++j) gin[r * G + j] = gin[r * G + j] + (bih[j] + bhh[j]);
+    int G = 4 * H, K = E + H;
+    float *Wcat = (float *)malloc((size_t)G * K * sizeof(float));     /* rows [Wih[j] | Whh[j]] */
+    for (int j = 0; j < G; ++j) {
+        memcpy(Wcat + (size_t)j * K, Wih + (size_t)j * E, (size_t)E * sizeof(float));
+        memcpy(Wcat + (size_t)j * K + E, Whh + (size_t)j * H, (size_t)H * sizeof(float));
+    }
+    float *Wt = transpose_nk(Wcat, G, K);
+    free(Wcat);
+    float *A = (float *)malloc((size_t)B * K * sizeof(float));
     float *h = (float *)calloc((size_t)B * H, sizeof(float));
     float *c = (float *)calloc((size_t)B * H, sizeof(float));
     float *gates = (float *)malloc((size_t)B * G * sizeof(float));
     for (int step = 0; step < T; ++step) {
         int t = reverse ? T - 1 - step : step;
-        chain_gemm(h, H, B, H, Whh_t, G, gin + (size_t)t * G, (long)T * G, gates, G);
+        for (long b = 0; b < B; ++b) {
+            memcpy(A + b * K, X + ((size_t)b * T + t) * E, (size_t)E * sizeof(float));
+            memcpy(A + b * K + E, h + b * H, (size_t)H * sizeof(float));
+        }
+        chain_gemm(A, K, B, K, Wt, G, NULL, 0, gates, G);
         for (long b = 0; b < B; ++b)
             for (int j = 0; j < H; ++j) {
                 const float *g4 = gates + b * G;
-                float ig = vfo_sigmoidf(g4[j]);
-                float fg = vfo_sigmoidf(g4[H + j]);
-                float gg = vfo_tanhf(g4[2 * H + j]);
-                float og = vfo_sigmoidf(g4[3 * H + j]);
+                float ig = vfo_sigmoidf(g4[j] + (bih[j] + bhh[j]));
+                float fg = vfo_sigmoidf(g4[H + j] + (bih[H + j] + bhh[H + j]));
+                float gg = vfo_tanhf(g4[2 * H + j] + (bih[2 * H + j] + bhh[2 * H + j]));
+                float og = vfo_sigmoidf(g4[3 * H + j] + (bih[3 * H + j] + bhh[3 * H + j]));
                 float cn = fmaf(fg, c[b * H + j], ig * gg);
                 c[b * H + j] = cn;
                 h[b * H + j] = og * vfo_tanhf(cn);
             }
     }
     for (long b = 0; b < B; ++b) memcpy(hout + b * ld, h + b * H, (size_t)H * sizeof(float));
-    free(Wih_t); free(Whh_t); free(gin); free(h); free(c); free(gates);
+    free(Wt); free(A); free(h); free(c); free(gates);
 }
 
 VFO_EXPORT void vfo_embed(const int64_t *tokens, long B, int T, const float *emb, const float *len_tab, int E, float *X)

@@ -3,9 +3,10 @@
 // one of the T steps processed (pads included, Q6) -> [h_fwd | h_bwd] -> Linear(2H, D).
 //
 //   X    [B*T, E]   = emb[tokens]                                   gather (+ optional normalise)
-//   Gin_d[B*T, 4H]  = X x Wih_d^T + (bih_d + bhh_d)                 hoisted input projection, d = fwd/bwd
-//   per step t:  gates = Gin_d[:, t] (C-in) + h_d x Whh_d^T         chain GEMM starting FROM the C-in
+//   per step t:  gates = [x_t | h_d] x [Wih_d | Whh_d]^T  (one chain over E + H)  + (bih_d + bhh_d)
 //                i,f,o = sigmoid, g = tanh; c' = fma(f, c, i*g); h' = o * tanh(c')
+//                -- ONE MFMA launch per step for both directions: segmented-K loader, gate-permuted tile
+//                   columns, pointwise epilogue (no hoisted Gin array, no gates array, no pointwise launch)
 //   out  [B, D]     = [h_fwd | h_bwd] x Wfc^T + bfc
 //
 // 352.4 MFLOP per query; the recurrent GEMM [B,H]x[H,4H] is the MFMA-bound part.
@@ -34,8 +35,10 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t *__restrict__ 
     for (int k = 0; k < E; ++k) x[k] = (e[k] / nrm) * len;
 }
 
-// gates [2][B,4H] -> c [2][B,H] (in place), h written into hcat [B, 2H] at column d*H
-__global__ __launch_bounds__(256) void lstm_pointwise_kernel(const float *__restrict__ gates, float *__restrict__ c,
+// gates [2][B,4H] (chains without bias) -> + (b_ih + b_hh) -> c [2][B,H] (in place), h into hcat [B,2H] at column d*H
+__global__ __launch_bounds__(256) void lstm_pointwise_kernel(const float *__restrict__ gates, const float *__restrict__ bih_f,
+                                                             const float *__restrict__ bhh_f, const float *__restrict__ bih_b,
+                                                             const float *__restrict__ bhh_b, float *__restrict__ c,
                                                              float *__restrict__ hcat, int64_t B, int H)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -44,18 +47,19 @@ __global__ __launch_bounds__(256) void lstm_pointwise_kernel(const float *__rest
     int d = (int)(i / per);
     int64_t r = i - d * per, b = r / H;
     int j = (int)(r - b * H);
+    const float *bih = d ? bih_b : bih_f, *bhh = d ? bhh_b : bhh_f;
     const float *g4 = gates + ((int64_t)d * B + b) * 4 * H;
-    float ig = c_sigmoidf(g4[j]);
-    float fg = c_sigmoidf(g4[H + j]);
-    float gg = c_tanhf(g4[2 * H + j]);
-    float og = c_sigmoidf(g4[3 * H + j]);
+    float ig = c_sigmoidf(g4[j] + (bih[j] + bhh[j]));
+    float fg = c_sigmoidf(g4[H + j] + (bih[H + j] + bhh[H + j]));
+    float gg = c_tanhf(g4[2 * H + j] + (bih[2 * H + j] + bhh[2 * H + j]));
+    float og = c_sigmoidf(g4[3 * H + j] + (bih[3 * H + j] + bhh[3 * H + j]));
     float cn = __builtin_fmaf(fg, c[i], ig * gg);
     c[i] = cn;
     hcat[b * 2 * H + (int64_t)d * H + j] = og * c_tanhf(cn);
 }
 
 struct LstmWs {
-    float *X, *gin[2], *gates, *c, *hcat;
+    float *X, *gates, *c, *hcat, *hcat2;
     size_t total;
 };
 static LstmWs carve(void *base, int64_t B, int T, int E, int H)
@@ -65,11 +69,10 @@ static LstmWs carve(void *base, int64_t B, int T, int E, int H)
     auto take = [&](size_t n) { float *p = reinterpret_cast<float *>(static_cast<char *>(base) + off);
                                 off += align_up(n * sizeof(float), 256); return p; };
     w.X = take((size_t)B * T * E);
-    w.gin[0] = take((size_t)B * T * 4 * H);
-    w.gin[1] = take((size_t)B * T * 4 * H);
     w.gates = take((size_t)2 * B * 4 * H);
     w.c = take((size_t)2 * B * H);
     w.hcat = take((size_t)B * 2 * H);
+    w.hcat2 = take((size_t)B * 2 * H);      // h ping-pong for the fused step kernel
     w.total = off;
     return w;
 }
@@ -109,37 +112,55 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
                        emb, len_tab, E, w.X);
     }
     VFR_CHECK_LAUNCH("embed_kernel");
-    {
-        vfr::GemmArgs g[2]{};
-        for (int d = 0; d < 2; ++d) {
-            g[d].A = w.X; g[d].lda = E; g[d].W = Wih[d]; g[d].ldw = E; g[d].out = w.gin[d]; g[d].ldo = G; g[d].M = B * T;
-            g[d].N = G; g[d].K = E; g[d].bias = bih[d]; g[d].bias2 = bhh[d]; g[d].epi = vfr::EPI_BIAS2;
-            g[d].site = vfr::SITE_GEMM_LSTM_IN;
-        }
-        if (int rc = vfr::gemm_nt_pair(g[0], g[1], st)) return rc;
-    }
     if (hipMemsetAsync(w.c, 0, (size_t)2 * B * H * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(w.hcat, 0, (size_t)B * 2 * H * sizeof(float), st) != hipSuccess)
         return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: hipMemsetAsync failed");
-    for (int step = 0; step < T; ++step) {
-        vfr::GemmArgs g[2]{};
-        for (int d = 0; d < 2; ++d) {
-            const int t = d ? T - 1 - step : step;
-            g[d].A = w.hcat + (size_t)d * H; g[d].lda = 2 * H; g[d].W = Whh[d]; g[d].ldw = H;
-            g[d].Cin = w.gin[d] + (size_t)t * G; g[d].ldc = (int64_t)T * G;
-            g[d].out = w.gates + (size_t)d * B * G; g[d].ldo = G; g[d].M = B; g[d].N = G; g[d].K = H;
-            g[d].site = vfr::SITE_GEMM_LSTM_REC;
+    float *h_final = w.hcat;
+    const bool fused = vfr::opt_gemm() != 0 && (E % 4) == 0 && (H % 4) == 0 &&
+                       ((((uintptr_t)Wih_f) | ((uintptr_t)Whh_f) | ((uintptr_t)Wih_b) | ((uintptr_t)Whh_b)) & 15) == 0;
+    if (fused) {
+        // one MFMA launch per time step for both directions: K = [x_t (E) | h (H)], gate epilogue fused
+        float *hin = w.hcat, *hout = w.hcat2;
+        for (int step = 0; step < T; ++step) {
+            vfr::GemmArgs g[2]{};
+            for (int d = 0; d < 2; ++d) {
+                const int t = d ? T - 1 - step : step;
+                g[d].A = w.X + (size_t)t * E; g[d].lda = (int64_t)T * E; g[d].W = Wih[d]; g[d].ldw = E; g[d].K = E;
+                g[d].A2 = hin + (size_t)d * H; g[d].lda2 = 2 * H; g[d].W2 = Whh[d]; g[d].ldw2 = H; g[d].K2 = H;
+                g[d].bias = bih[d]; g[d].bias2 = bhh[d]; g[d].M = B; g[d].N = G;
+                g[d].lstm_c = w.c + (size_t)d * B * H; g[d].lstm_h = hout + (size_t)d * H; g[d].lstm_ldh = 2 * H;
+                g[d].lstm_H = H; g[d].out = hout; g[d].site = vfr::SITE_GEMM_LSTM_REC;
+            }
+            if (int rc = vfr::lstm_step_pair(g[0], g[1], st)) return rc;
+            float *tmp = hin; hin = hout; hout = tmp;
         }
-        if (int rc = vfr::gemm_nt_pair(g[0], g[1], st)) return rc;      // forward + reverse as one grid
-        {
-        vfr::ProfScope prof(vfr::SITE_LSTM_POINTWISE, st);
-        hipLaunchKernelGGL(vfr::lstm_pointwise_kernel, dim3((unsigned)vfr::cdiv(2 * B * H, 256)), dim3(256), 0, st,
-                           w.gates, w.c, w.hcat, B, H);
+        h_final = hin;
+    } else {
+        // generic path (any E/H alignment, or the VALU cross-check build): same canonical order, unfused --
+        // x-part chain into gates, h-part chain continuing from it (C-in), then the pointwise kernel adds the biases
+        for (int step = 0; step < T; ++step) {
+            vfr::GemmArgs gx[2]{}, gh[2]{};
+            for (int d = 0; d < 2; ++d) {
+                const int t = d ? T - 1 - step : step;
+                gx[d].A = w.X + (size_t)t * E; gx[d].lda = (int64_t)T * E; gx[d].W = Wih[d]; gx[d].ldw = E;
+                gx[d].out = w.gates + (size_t)d * B * G; gx[d].ldo = G; gx[d].M = B; gx[d].N = G; gx[d].K = E;
+                gx[d].site = vfr::SITE_GEMM_LSTM_IN;
+                gh[d] = gx[d];
+                gh[d].A = w.hcat + (size_t)d * H; gh[d].lda = 2 * H; gh[d].W = Whh[d]; gh[d].ldw = H; gh[d].K = H;
+                gh[d].Cin = gx[d].out; gh[d].ldc = G; gh[d].site = vfr::SITE_GEMM_LSTM_REC;
+            }
+            if (int rc = vfr::gemm_nt_pair(gx[0], gx[1], st)) return rc;
+            if (int rc = vfr::gemm_nt_pair(gh[0], gh[1], st)) return rc;
+            {
+            vfr::ProfScope prof(vfr::SITE_LSTM_POINTWISE, st);
+            hipLaunchKernelGGL(vfr::lstm_pointwise_kernel, dim3((unsigned)vfr::cdiv(2 * B * H, 256)), dim3(256), 0, st,
+                               w.gates, bih_f, bhh_f, bih_b, bhh_b, w.c, w.hcat, B, H);
+            }
+            VFR_CHECK_LAUNCH("lstm_pointwise_kernel");
         }
-        VFR_CHECK_LAUNCH("lstm_pointwise_kernel");
     }
     vfr::GemmArgs g{};
-    g.A = w.hcat; g.lda = 2 * H; g.W = Wfc; g.ldw = 2 * H; g.out = out; g.ldo = D; g.M = B; g.N = D; g.K = 2 * H;
+    g.A = h_final; g.lda = 2 * H; g.W = Wfc; g.ldw = 2 * H; g.out = out; g.ldo = D; g.M = B; g.N = D; g.K = 2 * H;
     g.bias = bfc; g.epi = vfr::EPI_BIAS; g.site = vfr::SITE_GEMM_LANG_FC;
     return vfr::gemm_nt(g, st);
 }

@@ -9,6 +9,7 @@
 // Used by: visual MLP (model/models.py:21-26), BiLSTM input/recurrent projections and lang_fc
 // (model/models.py:40-47), BERT-branch Linear (:31), VGG fc6/fc7 (get_rgb_features.py:126).
 #include "vfr_common.h"
+#include "vfr_math.cuh"
 
 namespace vfr {
 
@@ -87,6 +88,9 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
 // fp32 MFMA runs at the fp32 vector rate (64 cycles per 32x32x2 per SIMD): this kernel is MFMA-pipe-bound,
 // staging has ~4096 cycles of cover per K-tile.
 // ------------------------------------------------------------------------------------------------
+#ifndef VFR_GEMM_SETPRIO
+#define VFR_GEMM_SETPRIO 1
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MBM = 128, MBN = 128, MBK = 32, MLD = 36;
 
@@ -107,7 +111,7 @@ __device__ __forceinline__ float4 load4_guard(const float *__restrict__ P, int64
 
 struct GemmPair { GemmArgs p[2]; };
 
-template <bool VEC, bool CONV>
+template <bool VEC, bool CONV, bool LSTM = false>
 __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
     // double-buffered tiles: [2][A 128x36 | W 128x36] floats = 73,728 B -> two workgroups per CU
@@ -133,12 +137,20 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // Staging loads.  Full K-tiles use UNCONDITIONAL loads (row index clamped into range; rows past M / N are
     // never stored) so the compiler can leave them in flight across the MFMA block -- a per-load bounds branch
     // makes hipcc drain vmcnt(0) right after issuing them.  Only the last, partial K-tile takes the guarded form.
-    const float *arow[4], *wrow[4];
+    const float *arow[4], *wrow[4], *arow2[4], *wrow2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
         const int64_t ma = m0 + row < g.M ? m0 + row : g.M - 1;
-        const int64_t nw = (int64_t)n0 + row < g.N ? (int64_t)n0 + row : g.N - 1;
+        int64_t nw = (int64_t)n0 + row < g.N ? (int64_t)n0 + row : g.N - 1;
+        if (LSTM) {   // tile row R = (wn, ni, l31): gate = 2*ni + (l31 >> 4), unit = 32*blockIdx.y + 16*wn + (l31 & 15)
+            const int gate = ((row >> 5) & 1) * 2 + ((row >> 4) & 1);
+            int unit = blockIdx.y * 32 + (row >> 6) * 16 + (row & 15);
+            unit = unit < g.lstm_H ? unit : g.lstm_H - 1;
+            nw = (int64_t)gate * g.lstm_H + unit;
+            arow2[i] = g.A2 + ma * g.lda2 + kk;
+            wrow2[i] = g.W2 + nw * g.ldw2 + kk;
+        }
         arow[i] = CONV ? g.A : g.A + ma * g.lda + kk;
         wrow[i] = g.W + nw * g.ldw + kk;
     }
@@ -196,7 +208,27 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             rw[i] = kok ? wv : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    const int nk_full = CONV ? (g.K + MBK - 1) / MBK : g.K / MBK;     // conv: every tile through the select loader
+    // ---- segmented-K loader (LSTM step): tiles [0, nk1) walk [A | W] over K, tiles [nk1, nk1+nk2) walk [A2 | W2]
+    // over K2; a partial tile is zero-selected after an unconditional clamped load (fma(0,0,acc) == acc).
+    const int nk1 = (g.K + MBK - 1) / MBK;
+    auto gload_seg = [&](int k0t) {
+        const int kt = k0t / MBK;
+        const bool second = kt >= nk1;
+        const int kk = (tid & 7) * 4, k = (second ? kt - nk1 : kt) * MBK + kk;
+        const bool kok = k < (second ? g.K2 : g.K);
+        const int kc = kok ? k : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *ap = (second ? arow2[i] : arow[i]) - kk + kc;
+            const float *wp = (second ? wrow2[i] : wrow[i]) - kk + kc;
+            const float4 av = *reinterpret_cast<const float4 *>(ap);
+            const float4 wv = *reinterpret_cast<const float4 *>(wp);
+            ra[i] = kok ? av : make_float4(0.f, 0.f, 0.f, 0.f);
+            rw[i] = kok ? wv : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    const int nk_full = LSTM ? nk1 + (g.K2 + MBK - 1) / MBK
+                             : CONV ? (g.K + MBK - 1) / MBK : g.K / MBK;     // conv / lstm: every tile through a select loader
     auto swrite = [&](int b) {
         float *As = lds + b * (MBM + MBN) * MLD, *Ws = As + MBM * MLD;
 #pragma unroll
@@ -236,27 +268,59 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // main loop over the FULL K-tiles, branch-free: iteration kt prefetches tile min(kt+1, last) (the final
     // iteration re-reads its own tile, which is harmless) so no control-flow join sits between the loads and the
     // MFMA block -- a join there makes the compiler drain vmcnt(0) before the first MFMA.
-    auto gload_main = [&](int k0) { if (CONV) gload_conv(k0); else gload_full(k0); };
+    auto gload_main = [&](int k0) { if (LSTM) gload_seg(k0); else if (CONV) gload_conv(k0); else gload_full(k0); };
     if (nk_full > 0) { gload_main(0); swrite(0); }
     __syncthreads();
     for (int kt = 0; kt < nk_full; ++kt) {
         const int nxt = kt + 1 < nk_full ? kt + 1 : nk_full - 1;
         gload_main(nxt * MBK);
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
+        if (VFR_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(1);
         compute(kt & 1);
+        if (VFR_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // the other buffer was last read in iteration kt-1 and every wave has passed that iteration's barrier:
         // refill it now (overlapping the other waves' MFMAs); one barrier per K-tile
         swrite((kt + 1) & 1);
         __syncthreads();
     }
-    if (!CONV && (g.K % MBK)) {            // partial last tile: guarded loads, zero padded (fma(0,0,acc) == acc)
+    if (!CONV && !LSTM && (g.K % MBK)) {   // partial last tile: guarded loads, zero padded (fma(0,0,acc) == acc)
         gload_tail(nk_full * MBK);
         swrite(nk_full & 1);
         __syncthreads();
         compute(nk_full & 1);
     }
 
+    if (LSTM) {
+        // lane l31 < 16 holds gates (i | g) of unit u in tiles ni = 0 | 1, lane l31 + 16 holds (f | o) of the same unit.
+        // The pair swaps what the other needs and splits the rows: the low lane finishes even r, the high lane odd r.
+        const int H = g.lstm_H, unit = blockIdx.y * 32 + wn * 16 + (l31 & 15);
+        const bool hi_lane = l31 >= 16, valid = unit < H;
+        const int uc = valid ? unit : H - 1;
+        const float bi = g.bias[uc] + g.bias2[uc], bf = g.bias[H + uc] + g.bias2[H + uc];
+        const float bg = g.bias[2 * H + uc] + g.bias2[2 * H + uc], bo = g.bias[3 * H + uc] + g.bias2[3 * H + uc];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p0 = __shfl_xor(acc[mi][0][r], 16, 64);      // partner's tile-0 gate (f for low, i for high)
+                const float p1 = __shfl_xor(acc[mi][1][r], 16, 64);      // partner's tile-1 gate (o for low, g for high)
+                const bool mine = ((r & 1) != 0) == hi_lane;
+                const int64_t row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (mine && valid && row < g.M) {
+                    const float xi = hi_lane ? p0 : acc[mi][0][r], xf = hi_lane ? acc[mi][0][r] : p0;
+                    const float xg = hi_lane ? p1 : acc[mi][1][r], xo = hi_lane ? acc[mi][1][r] : p1;
+                    const float ig = c_sigmoidf(xi + bi);
+                    const float fg = c_sigmoidf(xf + bf);
+                    const float gg = c_tanhf(xg + bg);
+                    const float og = c_sigmoidf(xo + bo);
+                    const float cn = __builtin_fmaf(fg, g.lstm_c[row * H + unit], ig * gg);
+                    g.lstm_c[row * H + unit] = cn;
+                    g.lstm_h[row * g.lstm_ldh + unit] = og * c_tanhf(cn);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -286,6 +350,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp) { gemm_
 
 __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true>(g); }
 
+__global__ __launch_bounds__(256, 2) void lstm_step_mfma_pair(GemmPair gp) { gemm_nt_mfma_body<true, false, true>(gp.p[blockIdx.z]); }
+
 __global__ __launch_bounds__(256) void repack_rows_kernel(const float *__restrict__ src, int64_t ld_src, int rows, int cols,
                                                           float *__restrict__ dst)
 {
@@ -308,6 +374,24 @@ int repack_rows(const float *src, int64_t ld_src, int rows, int cols, float *dst
 static bool gemm_vec_ok(const GemmArgs &g)
 {
     return ((g.lda | g.ldw) & 3) == 0 && ((((uintptr_t)g.A) | ((uintptr_t)g.W)) & 15) == 0;
+}
+
+int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
+{
+    if (g0.M == 0) return VFR_OK;
+    for (const GemmArgs *g : {&g0, &g1}) {
+        VFR_REQUIRE(g->A && g->W && g->A2 && g->W2 && g->bias && g->bias2 && g->lstm_c && g->lstm_h && g->lstm_H > 0, VFR_EINVAL,
+                    "lstm_step_pair: bad argument");
+        VFR_REQUIRE(((g->lda | g->ldw | g->lda2 | g->ldw2 | g->K | g->K2) & 3) == 0 &&
+                        ((((uintptr_t)g->A) | ((uintptr_t)g->W) | ((uintptr_t)g->A2) | ((uintptr_t)g->W2)) & 15) == 0,
+                    VFR_EUNSUPPORTED, "lstm_step_pair: E, H and the operand strides must be multiples of 4 floats, 16-byte aligned");
+    }
+    ProfScope prof(g0.site, st);
+    GemmPair gp{{g0, g1}};
+    dim3 grid((unsigned)cdiv(g0.M, MBM), (unsigned)cdiv(g0.lstm_H, 32), 2);
+    hipLaunchKernelGGL(lstm_step_mfma_pair, grid, dim3(256), 0, st, gp);
+    VFR_CHECK_LAUNCH("lstm_step_mfma_pair");
+    return VFR_OK;
 }
 
 int gemm_nt_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)

@@ -74,11 +74,19 @@ struct GemmArgs {
     // output pixel (n, oy, ox), column k = (ky*3 + kx)*conv_cin + ci reads x[n][oy+ky-1][ox+kx-1][ci] (0 outside).
     // M = B*conv_h*conv_w, K = 9*conv_cin (conv_cin % 4 == 0), out [M, N] is the NHWC output.
     int conv_h, conv_w, conv_cin;
+    // fused LSTM step (lstm_H > 0): K is segmented, A row = [A (K cols) | A2 (K2 cols)], W row = [W | W2]; the 128 tile
+    // columns are 32 hidden units x 4 gates (permuted so one lane pair holds i,f,g,o of a unit); the epilogue adds
+    // bias + bias2, applies the gate nonlinearities and writes c (in place) and h_out -- no gates array.
+    // N (grid) = lstm_H hidden units, bias / bias2 are the [4H] b_ih / b_hh.
+    const float *A2; int64_t lda2; const float *W2; int64_t ldw2; int K2;
+    float *lstm_c; float *lstm_h; int64_t lstm_ldh; int lstm_H;
 };
 int gemm_nt(const GemmArgs &g, hipStream_t st);
 // two GEMMs of identical shape as ONE grid (blockIdx.z picks the problem): fills the chip when one alone leaves a
 // partial last round (the forward and reverse LSTM directions)
 int gemm_nt_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st);
+// fused LSTM step for both directions (see GemmArgs::lstm_H)
+int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st);
 // copy a [rows, cols] block out of a wider row-major matrix into a dense, 16-byte aligned buffer
 int repack_rows(const float *src, int64_t ld_src, int rows, int cols, float *dst, hipStream_t st);
 
