@@ -88,8 +88,11 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
 // fp32 MFMA runs at the fp32 vector rate (64 cycles per 32x32x2 per SIMD): this kernel is MFMA-pipe-bound,
 // staging has ~4096 cycles of cover per K-tile.
 // ------------------------------------------------------------------------------------------------
+#ifndef VFR_GEMM_NBUF
+#define VFR_GEMM_NBUF 2      // LDS tile buffers: 2 = double buffered (2 workgroups/CU), 1 = single (3 workgroups/CU)
+#endif
 #ifndef VFR_GEMM_SETPRIO
-#define VFR_GEMM_SETPRIO 1
+#define VFR_GEMM_SETPRIO 0
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MBM = 128, MBN = 128, MBK = 32, MLD = 36;
@@ -115,7 +118,7 @@ template <bool VEC, bool CONV, bool LSTM = false>
 __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
     // double-buffered tiles: [2][A 128x36 | W 128x36] floats = 73,728 B -> two workgroups per CU
-    __shared__ __attribute__((aligned(16))) float lds[2 * (MBM + MBN) * MLD];
+    __shared__ __attribute__((aligned(16))) float lds[VFR_GEMM_NBUF * (MBM + MBN) * MLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * MBM;
@@ -276,19 +279,20 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         gload_main(nxt * MBK);
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
         if (VFR_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(1);
-        compute(kt & 1);
+        compute(kt % VFR_GEMM_NBUF);
         if (VFR_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // the other buffer was last read in iteration kt-1 and every wave has passed that iteration's barrier:
         // refill it now (overlapping the other waves' MFMAs); one barrier per K-tile
-        swrite((kt + 1) & 1);
+        if (VFR_GEMM_NBUF == 1) __syncthreads();     // single buffer: everyone must finish reading before the refill
+        swrite((kt + 1) % VFR_GEMM_NBUF);
         __syncthreads();
     }
     if (!CONV && !LSTM && (g.K % MBK)) {   // partial last tile: guarded loads, zero padded (fma(0,0,acc) == acc)
         gload_tail(nk_full * MBK);
-        swrite(nk_full & 1);
+        swrite(nk_full % VFR_GEMM_NBUF);
         __syncthreads();
-        compute(nk_full & 1);
+        compute(nk_full % VFR_GEMM_NBUF);
     }
 
     if (LSTM) {
@@ -343,7 +347,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_nt_mfma(GemmArgs g) { gemm_nt_mfma_body<VEC, false>(g); }
+__global__ __launch_bounds__(256, VFR_GEMM_NBUF == 1 ? 3 : 2) void gemm_nt_mfma(GemmArgs g) { gemm_nt_mfma_body<VEC, false>(g); }
 
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp) { gemm_nt_mfma_body<VEC, false>(gp.p[blockIdx.z]); }
