@@ -404,8 +404,7 @@ __device__ __attribute__((noinline)) void lane_tighten(unsigned long long *col, 
     }
 }
 
-template <int NT> struct FastCfg { static constexpr int NC = 4; };
-template <> struct FastCfg<6> { static constexpr int NC = 3; };
+template <int NT> struct FastCfg { static constexpr int NC = 3; };   // 6 = 2 x 3 and 21 = 7 x 3: no wasted clip slots
 
 // Thresholds are kept as EXCLUSIVE upper bounds on the fp32 bit pattern of the (non-negative) sum:
 //   score <  x  <=>  bits(sum) < LOX,   score <= x  <=>  bits(sum) < HIX = LOX + delta   (delta in 0..3)
@@ -422,9 +421,9 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
     constexpr int CAP = KPL * 64, NC = FastCfg<NT>::NC, ROW4 = FAST_D / 4, G4 = NC * ROW4;   // float4 per group
     constexpr int NLD = (G4 + 63) / 64;                                                       // loads per lane
     constexpr int NRR = NR > 0 ? NR : 1;
-    // the one combination that would not fit 256 registers (n = 21, top-k AND rank keys) keeps its rank bounds in LDS
-    // ([r][L][lane] column, 2 ds_read per span length) -- 19.4 KB per wave, so 8 waves/CU still fit in 160 KB
-    constexpr bool LOX_LDS = NT > 6 && NR > 0 && TOPK;
+    // n = 21 with rank keys keeps the per-length rank bounds in LDS ([r][L][lane] column, 2 ds_read per span length):
+    // 42 registers fewer; 18.5 KB of LDS per wave, so 8 waves/CU still fit in 160 KB
+    constexpr bool LOX_LDS = NT > 6 && NR > 0;
     const int lane = threadIdx.x;
     const int task = blockIdx.x;
     const int chunk = task / a.num_groups, group = task - chunk * a.num_groups;
@@ -560,7 +559,10 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
             swrite(buf);
         }
         // ---- moment triangle, L-outer, fully unrolled: sums[] and the tables are static registers ----
-        float sums[NT];
+        // all n clip distances into registers in one burst (one wait), then the triangle touches no memory
+        float d[NT], sums[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) d[c] = (EXACT || c < n) ? ds[c * 64 + lane] : __builtin_inff();
         bool tie = wide;
 #pragma unroll
         for (int L = 1; L <= NT; ++L) {
@@ -573,7 +575,7 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
 #pragma unroll
             for (int s = 0; s + L <= NT; ++s) {
                 if (EXACT || s + L <= n) {                 // wave-uniform
-                    const float de = ds[(s + L - 1) * 64 + lane];
+                    const float de = d[s + L - 1];
                     const float sum = L == 1 ? de : sums[s] + de;
                     sums[s] = sum;
                     const unsigned sb = __float_as_uint(sum);
@@ -857,11 +859,11 @@ static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st, int *cap_tr
         const int NT = NTsel;
         kpl = a.k + Msel <= 256 ? 4 : 8;                   // candidate columns hold k kept + one video's worth
         if (cap_transposed && a.k > 0) *cap_transposed = kpl * 64;
-        const bool lox_lds = NT > 6 && a.num_rank > 0 && a.k > 0 && !opt_score_split();
-        // every video has exactly NT clips: no length guards (the fused n=21 kernel keeps them: without the guards'
-        // scalar branches hipcc hoists the unrolled triangle's LDS reads and spills)
-        const bool exact = a.min_clips == NT && !lox_lds;
-        const int NCg = NT == 6 ? 3 : 4, rows = (NT + NCg - 1) / NCg * NCg;
+        const bool lox_lds = NT > 6 && a.num_rank > 0;
+        // every video has exactly NT clips: no length guards.  (The fused n = 21 top-k + rank instantiation keeps them:
+        // without the guards' scalar branches hipcc's schedule of the straight-line triangle spills ~900 B/lane.)
+        const bool exact = a.min_clips == NT && !(lox_lds && a.k > 0);
+        const int NCg = 3, rows = (NT + NCg - 1) / NCg * NCg;
         const size_t lds = ((size_t)2 * NCg * FAST_D + (size_t)rows * 64 + (lox_lds ? (size_t)a.num_rank * NT * 64 : 0)) * sizeof(float);
         dim3 grid((unsigned)tasks);
         if (NT == 6) { if (exact) launch_fast_nt<6, true>(a, kpl, grid, lds, st); else launch_fast_nt<6, false>(a, kpl, grid, lds, st); }
