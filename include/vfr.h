@@ -104,6 +104,9 @@ int vfr_score_own_f32(const float *Q, int64_t Nq, const float *V, const int32_t 
  *           += number of moments that sort strictly before (rank_dist[r][q], rank_idx[r][q]) --
  *           evaluate.py:77's MR when that pair is the best ground-truth-positive moment of IoU
  *           threshold r.  Counts are ADDED (zero the array first, or chain shards).
+ * thr_seed (nullable, [Nq] packed keys (fp32 bits of distance << 32 | id)): an upper bound on each query's k-th best
+ *           key, known to the caller (the merged sample of all shards, 8e).  Only keys below it are collected and the
+ *           internal sample pre-pass is skipped; results are exact for any valid bound.
  * id_base is added to every emitted / compared moment id (shard offset for multi-GPU, 8e).
  * min_clips / max_clips: smallest / largest clip count in the bank (min_clips 0 = unknown; when
  * min == max the kernels drop their per-video length guards).
@@ -112,8 +115,8 @@ size_t vfr_score_topk_workspace_bytes(int64_t Nq, int Nv, int k);
 int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets,
                        const int64_t *moment_offsets, int Nv, int total_clips, int min_clips, int max_clips, int D,
                        float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
-                       const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, void *workspace,
-                       size_t workspace_bytes, vfr_stream_t stream);
+                       const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, const int64_t *thr_seed,
+                       void *workspace, size_t workspace_bytes, vfr_stream_t stream);
 /* merge G per-shard top-k lists (after the RCCL all-gather): part_dist/part_idx
  * [G, Nq, k] -> out [Nq, k], same (distance, id) order.                                        */
 int vfr_topk_merge_f32(const float *part_dist, const int64_t *part_idx, int G, int64_t Nq, int k, float *out_dist,

@@ -208,6 +208,34 @@ def test_topk_merge_and_shard_equivalence(vfr, oracle):
     assert cnt[0].cpu().numpy().tolist() == oracle.rank_of(Q, V, off, rd, pick).tolist()
 
 
+def test_seeded_sharded_search_equals_unsharded(vfr, oracle):
+    """The multi-GPU flow of engine.sharded_search replayed on one device: per-shard sample lists -> merged global
+    sample -> its k-th key as thr_seed for the main passes -> merge(main parts + sample) == unsharded top-k."""
+    from vfr_amd import engine
+    rs = np.random.RandomState(21)
+    counts = synth.clip_counts(3000, 21, seed=21)
+    off = synth.clip_offsets(counts)
+    V = rs.randn(int(off[-1]), 100).astype(np.float32) * 0.1
+    Q = rs.randn(96, 100).astype(np.float32) * 0.1
+    k = 100
+    bank = _bank(vfr, V, off)
+    wd, wi, _ = vfr.score_topk(dev(Q), bank, k)                    # unsharded (internal pre-pass path: Nv >= 2048)
+    od, oi = oracle.score_topk(Q, V, off, k)
+    assert same(wi, oi) and same(wd, od)
+    shards = [(0, 1400), (1400, 3000)]
+    samples, mains = [], []
+    for lo, hi in shards:
+        sb = vfr.slice_bank(bank, counts, lo, lo + 128)
+        samples.append(vfr.score_topk(dev(Q), sb, k)[:2])
+    sd, si = vfr.topk_merge(torch.stack([s[0] for s in samples]), torch.stack([s[1] for s in samples]))
+    seed = engine._pack_key(sd[:, k - 1].contiguous(), si[:, k - 1])
+    for lo, hi in shards:
+        mb = vfr.slice_bank(bank, counts, lo + 128, hi)
+        mains.append(vfr.score_topk(dev(Q), mb, k, thr_seed=seed)[:2])
+    md, mi = vfr.topk_merge(torch.stack([m[0] for m in mains] + [sd]), torch.stack([m[1] for m in mains] + [si]))
+    assert same(mi, oi) and same(md, od)
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tag,clips", [("n6", 6), ("ragged", "didemo"), ("n21", 21)])
 def test_evaluators_end_to_end_on_gpu(vfr, oracle, golden, tag, clips):

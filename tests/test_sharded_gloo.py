@@ -20,12 +20,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, clips, out_dir):
+def _worker(rank, world, port, clips, out_dir, sample=256):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from vfr_amd import engine
         from vfr_amd import evaluate as vevaluate
+        engine.SAMPLE_VIDEOS = sample          # small sample: both the sample part and the seeded main part are non-empty
         p = problem(37, 23, clips, feat_dim=64, hidden=16)          # odd sizes: uneven shards, padded query split
         ds = MemoryDataset(p["seg"], p["ctx"], p["counts"], p["tokens"], p["own"], p["times"])
         model = make_model(p["sd"], feat_dim=64, hidden=16)
@@ -37,11 +39,11 @@ def _worker(rank, world, port, clips, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("clips", [6, "didemo"])
-def test_two_rank_sharded_evaluate_equals_single_process(tmp_path, clips):
+@pytest.mark.parametrize("clips,sample", [(6, 256), ("didemo", 256), ("didemo", 8)])
+def test_two_rank_sharded_evaluate_equals_single_process(tmp_path, clips, sample):
     from vfr_amd import evaluate as vevaluate
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), clips, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), clips, str(tmp_path), sample), nprocs=world, join=True)
     p = problem(37, 23, clips, feat_dim=64, hidden=16)
     ds = MemoryDataset(p["seg"], p["ctx"], p["counts"], p["tokens"], p["own"], p["times"])
     vi, li = ds.iterators()

@@ -41,7 +41,7 @@ SIGNATURES = {
     "vfr_score_own_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp]),
     "vfr_score_topk_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "vfr_score_topk_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i64, _i32, _vp, _vp, _i32,
-                                  _vp, _vp, _vp, _vp, _sz, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vfr_topk_merge_f32": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "vfr_frames_normalize_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "vfr_conv3x3_relu_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
@@ -235,6 +235,19 @@ class VideoBank:
         self.dim = int(self.emb.shape[1])
 
 
+def slice_bank(bank: VideoBank, counts, v0: int, v1: int) -> VideoBank:
+    """Videos [v0, v1) of ``bank`` as a bank of their own (``counts`` = host clip counts of ``bank``'s videos)."""
+    import numpy as np
+    counts = np.asarray(counts, np.int64)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    mom = np.concatenate([[0], np.cumsum(counts * (counts + 1) // 2)])
+    sub = counts[v0:v1]
+    clip_off = torch.from_numpy((off[v0:v1 + 1] - off[v0]).astype(np.int32)).to(bank.emb.device)
+    return VideoBank(bank.emb[int(off[v0]):int(off[v1])], clip_off, bank.id_base + int(mom[v0]),
+                     max_clips=int(sub.max()) if len(sub) else 0, total_moments=int(mom[v1] - mom[v0]),
+                     min_clips=int(sub.min()) if len(sub) else 0)
+
+
 def score_moments(Q: torch.Tensor, bank: VideoBank, eps: float = 1e-6) -> torch.Tensor:
     Q = _dev(Q, torch.float32, "Q")
     out = torch.empty((Q.shape[0], bank.total_moments), dtype=torch.float32, device=Q.device)
@@ -256,7 +269,7 @@ def score_own(Q: torch.Tensor, bank: VideoBank, own: torch.Tensor, eps: float = 
 
 
 def score_topk(Q: torch.Tensor, bank: VideoBank, k: int, rank_dist=None, rank_idx=None, count_lt=None,
-               eps: float = 1e-6, workspace: torch.Tensor | None = None):
+               eps: float = 1e-6, workspace: torch.Tensor | None = None, thr_seed: torch.Tensor | None = None):
     """Fused scoring + top-k (+ rank counting for up to 4 keys per query).
 
     rank_dist / rank_idx: [R, Nq] (or [Nq]) -> count_lt [R, Nq] int64 is ADDED to (allocated zeroed when None).
@@ -273,13 +286,15 @@ def score_topk(Q: torch.Tensor, bank: VideoBank, k: int, rank_dist=None, rank_id
         if count_lt is None:
             count_lt = torch.zeros((R, Nq), dtype=torch.int64, device=Q.device)
         count_lt = _dev(count_lt, torch.int64, "count_lt")
+    if thr_seed is not None:
+        thr_seed = _dev(thr_seed, torch.int64, "thr_seed")
     nbytes = lib().vfr_score_topk_workspace_bytes(Nq, bank.num_videos, k)
     if workspace is None or workspace.numel() < nbytes:
         workspace = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=Q.device)
     _check(lib().vfr_score_topk_f32(Q.data_ptr(), Nq, bank.emb.data_ptr(), bank.clip_off.data_ptr(),
                                     bank.mom_off.data_ptr(), bank.num_videos, bank.total_clips, bank.min_clips,
                                     bank.max_clips, bank.dim, eps, bank.id_base, k, _ptr(od), _ptr(oi), R, _ptr(rank_dist),
-                                    _ptr(rank_idx), _ptr(count_lt), workspace.data_ptr(), nbytes, _stream()),
+                                    _ptr(rank_idx), _ptr(count_lt), _ptr(thr_seed), workspace.data_ptr(), nbytes, _stream()),
            "vfr_score_topk_f32")
     return od, oi, count_lt
 

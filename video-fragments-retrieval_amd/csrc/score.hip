@@ -929,8 +929,8 @@ size_t vfr_score_topk_workspace_bytes(int64_t Nq, int Nv, int k)
 int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets,
                        const int64_t *moment_offsets, int Nv, int total_clips, int min_clips, int max_clips, int D,
                        float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
-                       const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, void *workspace,
-                       size_t workspace_bytes, vfr_stream_t stream)
+                       const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, const int64_t *thr_seed,
+                       void *workspace, size_t workspace_bytes, vfr_stream_t stream)
 {
     VFR_REQUIRE(num_rank >= 0 && num_rank <= vfr::MAX_RANK, VFR_EUNSUPPORTED, "vfr_score_topk_f32: num_rank=%d > %d",
                 num_rank, vfr::MAX_RANK);
@@ -972,12 +972,15 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
                                capt, ex, okeys, seed, od, oi);
     };
     if (Nv > 0) {
-        if (k > 0 && hipMemsetAsync(w.thr, 0xFF, (size_t)Nq * 8, st) != hipSuccess)
-            return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: hipMemsetAsync failed");
+        if (k > 0) {
+            const hipError_t e = thr_seed ? hipMemcpyAsync(w.thr, thr_seed, (size_t)Nq * 8, hipMemcpyDeviceToDevice, st)
+                                          : hipMemsetAsync(w.thr, 0xFF, (size_t)Nq * 8, st);
+            if (e != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: threshold initialisation failed");
+        }
         // sample pre-pass (fast path only, corpus large enough): exact top-k of the first PRE_VIDEOS videos; its k-th
         // key seeds thr_global, so the main pass appends ~k*Nv/PRE_VIDEOS candidates per query and never has to
         // tighten.  The rank counters always run over the whole range in the main launch.
-        const bool prepass = k > 0 && vfr::fast_applicable(a) && Nv >= 8 * vfr::PRE_VIDEOS;
+        const bool prepass = k > 0 && !thr_seed && vfr::fast_applicable(a) && Nv >= 8 * vfr::PRE_VIDEOS;
         if (prepass) {
             vfr::ScoreArgs pre = a;
             pre.v_lo = 0; pre.v_hi = vfr::PRE_VIDEOS; pre.num_chunks = vfr::PRE_CHUNKS; pre.num_rank = 0;

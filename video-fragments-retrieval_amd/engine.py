@@ -45,8 +45,12 @@ class HipOps:
     def score_own(self, Q, bank, own_local):
         return self.v.score_own(Q, bank, own_local)
 
-    def score_topk(self, Q, bank, k, rank_dist, rank_idx, workspace=None):
-        return self.v.score_topk(Q, bank, k, rank_dist, rank_idx, workspace=workspace)
+    def score_topk(self, Q, bank, k, rank_dist, rank_idx, workspace=None, count_lt=None, thr_seed=None):
+        return self.v.score_topk(Q, bank, k, rank_dist, rank_idx, count_lt=count_lt, workspace=workspace,
+                                 thr_seed=thr_seed)
+
+    def slice_bank(self, bank, counts, v0, v1):
+        return self.v.slice_bank(bank, counts, v0, v1)
 
     def topk_merge(self, part_dist, part_idx):
         return self.v.topk_merge(part_dist, part_idx)
@@ -212,31 +216,63 @@ def corpus_ranks(shard: CorpusShard, Q, own_global, labels, ops=None, k=0, world
     if bool((keys == KEY_INF).any()):
         raise IndexError("index 0 is out of bounds for axis 0 with size 0 (no ground-truth-positive moment)")
     rank_dist, rank_idx = _unpack_key(keys)
-    od, oi, counts = ops.score_topk(Q, shard.bank, k, rank_dist.contiguous(), rank_idx.contiguous(), workspace=workspace)
-    dist = _dist() if world > 1 else None
-    if dist is not None:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        if k > 0:
-            od, oi = gather_merge_topk(od, oi, ops, world)
+    od, oi, counts = sharded_search(shard, Q, k, rank_dist.contiguous(), rank_idx.contiguous(), ops, world, workspace)
     return counts, od, oi
 
 
 def corpus_topk(shard: CorpusShard, Q, k, ops=None, world=1, workspace=None):
     ops = ops or HipOps()
-    od, oi, _ = ops.score_topk(Q, shard.bank, k, None, None, workspace=workspace)
-    if world > 1 and _dist() is not None:
-        od, oi = gather_merge_topk(od, oi, ops, world)
+    od, oi, _ = sharded_search(shard, Q, k, None, None, ops, world, workspace)
     return od, oi
 
 
-def gather_merge_topk(od, oi, ops, world):
-    """The one exchange step of the path: all_gather the per-shard [Nq, k] lists (dist and ids as one packed
-    int64 key tensor -> a single collective), then merge with the (distance, id) tie-break."""
+SAMPLE_VIDEOS = 256      # corpus-wide size of the threshold sample (the single-GPU kernel samples the same number itself)
+
+
+def sharded_search(shard: CorpusShard, Q, k, rank_dist, rank_idx, ops, world=1, workspace=None):
+    """Fused scoring of one shard plus the exchange steps of SURVEY.md 8e.  Returns (dist, idx, counts).
+
+    world == 1: one call (the kernel runs its own sample pre-pass).  world > 1 with k > 0: the threshold sample is
+    split over the ranks so its cost scales too -- every rank scores its first 256/world videos exactly, the
+    per-rank sample lists are all-gathered and merged into the GLOBAL sample top-k, whose k-th key seeds every
+    rank's main pass over the rest of its shard (``thr_seed``); the final lists (main parts + the sample list) are
+    all-gathered and merged once more.  Rank counts are summed with one all_reduce."""
+    dist = _dist() if world > 1 else None
+    if dist is None or k == 0:
+        od, oi, counts = ops.score_topk(Q, shard.bank, k, rank_dist, rank_idx, workspace=workspace)
+        if dist is not None and counts is not None:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        return od, oi, counts
+    nloc = shard.hi - shard.lo
+    counts_loc = shard.counts_all[shard.lo:shard.hi]
+    s_r = min(nloc, max(1, -(-SAMPLE_VIDEOS // world)))
+    bank_a = ops.slice_bank(shard.bank, counts_loc, 0, s_r)
+    d_a, i_a, cnt = ops.score_topk(Q, bank_a, k, rank_dist, rank_idx, workspace=workspace)
+    s_d, s_i = gather_merge_topk(d_a, i_a, ops, world)                        # global sample top-k, every rank
+    seed = torch.where(s_i[:, k - 1] >= 0, _pack_key(s_d[:, k - 1].contiguous(), s_i[:, k - 1].clamp(min=0)),
+                       torch.full_like(s_i[:, k - 1], KEY_INF)).contiguous()
+    if s_r < nloc:
+        bank_b = ops.slice_bank(shard.bank, counts_loc, s_r, nloc)
+        d_b, i_b, cnt = ops.score_topk(Q, bank_b, k, rank_dist, rank_idx, workspace=workspace, count_lt=cnt, thr_seed=seed)
+    else:
+        d_b, i_b = torch.full_like(d_a, float("inf")), torch.full_like(i_a, -1)
+    if cnt is not None:
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    od, oi = gather_merge_topk(d_b, i_b, ops, world, extra=(s_d, s_i))
+    return od, oi, cnt
+
+
+def gather_merge_topk(od, oi, ops, world, extra=None):
+    """Exchange step: all_gather the per-shard [Nq, k] lists (dist and ids as one packed int64 key tensor -> a
+    single collective), then merge with the (distance, id) tie-break.  ``extra`` = an additional (dist, idx) list
+    every rank already holds (the global sample top-k)."""
     dist = _dist()
     packed = torch.where(oi >= 0, _pack_key(od, oi.clamp(min=0)), torch.full_like(oi, KEY_INF))
     parts = [torch.empty_like(packed) for _ in range(world)]
     dist.all_gather(parts, packed)
-    allk = torch.stack(parts)                                             # [G, Nq, k]
+    if extra is not None:
+        parts.append(torch.where(extra[1] >= 0, _pack_key(extra[0], extra[1].clamp(min=0)), torch.full_like(extra[1], KEY_INF)))
+    allk = torch.stack(parts)                                             # [G (+1), Nq, k]
     pd, pi = _unpack_key(allk)
     pi = torch.where(allk == KEY_INF, torch.full_like(pi, -1), pi)
     return ops.topk_merge(pd.contiguous(), pi.contiguous())
@@ -307,14 +343,23 @@ class TorchCpuOps:
             out[q, :sc.numel()] = sc
         return out
 
-    def score_topk(self, Q, bank, k, rank_dist, rank_idx, workspace=None):
-        sc = self._dense(Q, bank)
+    def slice_bank(self, bank, counts, v0, v1):
+        counts = np.asarray(counts, np.int64)
+        off = np.concatenate([[0], np.cumsum(counts)])
+        mom = np.concatenate([[0], np.cumsum(counts * (counts + 1) // 2)])
+        clip_off = torch.from_numpy((off[v0:v1 + 1] - off[v0]).astype(np.int32))
+        return TorchCpuOps.Bank(bank.emb[int(off[v0]):int(off[v1])], clip_off, bank.id_base + int(mom[v0]))
+
+    def score_topk(self, Q, bank, k, rank_dist, rank_idx, workspace=None, count_lt=None, thr_seed=None):
+        sc = self._dense(Q, bank)            # thr_seed is only an accelerator: the exact result does not depend on it
         ids = bank.id_base + torch.arange(sc.shape[1])
         keys = _pack_key(sc, ids[None, :].expand_as(sc))
         counts = None
         if rank_dist is not None:
             kstar = _pack_key(rank_dist.reshape(-1, Q.shape[0]), rank_idx.reshape(-1, Q.shape[0]))
             counts = (keys[None, :, :] < kstar[:, :, None]).sum(-1)
+            if count_lt is not None:
+                counts = counts + count_lt
         od = oi = None
         if k > 0:
             srt = keys.sort(dim=1).values[:, :k]
