@@ -108,11 +108,19 @@ def main():
     import vfr_amd  # noqa: F401
     from vfr_amd import _vfr, engine, models, synth
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU substitute)"
+    # rehearsal switches (not used by the driver): VFR_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and
+    # VFR_BENCH_BACKEND=gloo swaps RCCL for gloo, so the multi-rank code path can be exercised on a one-GPU box
+    if os.environ.get("VFR_BENCH_SAME_DEVICE"):
+        local = 0
+    backend = os.environ.get("VFR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         dist = None
 

@@ -853,7 +853,7 @@ static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st, int *cap_tr
 {
     if (cap_transposed) *cap_transposed = 0;
     const int tasks = a.num_groups * a.num_chunks;
-    ProfScope prof(MODE == 0 ? SITE_SCORE_DENSE : a.force_generic ? SITE_SCORE_PREPASS : a.k == 0 ? SITE_SCORE_RANK : SITE_SCORE_FUSED, st);
+    ProfScope prof(MODE == 0 ? SITE_SCORE_DENSE : (a.force_generic && a.k > 0) ? SITE_SCORE_PREPASS : a.k == 0 ? SITE_SCORE_RANK : SITE_SCORE_FUSED, st);
     const int NTsel = a.ds_rows <= 6 ? 6 : 21, Msel = NTsel * (NTsel + 1) / 2;
     if (MODE == 1 && fast_applicable(a) && !a.force_generic) {
         const int NT = NTsel;
@@ -980,7 +980,15 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
         // sample pre-pass (fast path only, corpus large enough): exact top-k of the first PRE_VIDEOS videos; its k-th
         // key seeds thr_global, so the main pass appends ~k*Nv/PRE_VIDEOS candidates per query and never has to
         // tighten.  The rank counters always run over the whole range in the main launch.
-        const bool prepass = k > 0 && !thr_seed && vfr::fast_applicable(a) && Nv >= 8 * vfr::PRE_VIDEOS;
+        const bool prepass = k > 0 && !thr_seed && vfr::fast_applicable(a) && Nv >= 4 * vfr::PRE_VIDEOS;
+        // small banks (a per-rank threshold sample, smoke-sized corpora): warm-up dominates, so use the
+        // cooperative-compaction kernel with ~10 videos per task instead of many one-video tasks whose unsorted
+        // output the merge kernel would have to sort
+        if (k > 0 && !thr_seed && Nv <= 2 * vfr::PRE_VIDEOS) {
+            a.force_generic = 1;
+            const int c = Nv / 10 < 1 ? 1 : Nv / 10;
+            a.num_chunks = c < a.num_chunks ? c : a.num_chunks;
+        }
         if (prepass) {
             vfr::ScoreArgs pre = a;
             pre.v_lo = 0; pre.v_hi = vfr::PRE_VIDEOS; pre.num_chunks = vfr::PRE_CHUNKS; pre.num_rank = 0;
