@@ -245,12 +245,24 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         const float *As = lds + b * (MBM + MBN) * MLD, *Ws = As + MBM * MLD;
         const float *ap = &As[(wm * 64 + l31) * MLD];
         const float *wp = &Ws[(wn * 64 + l31) * MLD];
+        // fragment double buffer: the four ds_read_b128 of slice k4+1 are issued (and pinned) BEFORE the eight MFMAs
+        // of slice k4, so their latency hides under the matrix pipe instead of sitting between MFMA groups
+        float4 fa[2][2], fb[2][2];
+        fa[0][0] = *reinterpret_cast<const float4 *>(ap);
+        fa[0][1] = *reinterpret_cast<const float4 *>(ap + 32 * MLD);
+        fb[0][0] = *reinterpret_cast<const float4 *>(wp);
+        fb[0][1] = *reinterpret_cast<const float4 *>(wp + 32 * MLD);
 #pragma unroll
         for (int k4 = 0; k4 < MBK / 4; ++k4) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(ap + k4 * 4);
-            const float4 a1 = *reinterpret_cast<const float4 *>(ap + 32 * MLD + k4 * 4);
-            const float4 b0 = *reinterpret_cast<const float4 *>(wp + k4 * 4);
-            const float4 b1 = *reinterpret_cast<const float4 *>(wp + 32 * MLD + k4 * 4);
+            const int cur = k4 & 1, nxt = cur ^ 1;
+            if (k4 + 1 < MBK / 4) {
+                fa[nxt][0] = *reinterpret_cast<const float4 *>(ap + (k4 + 1) * 4);
+                fa[nxt][1] = *reinterpret_cast<const float4 *>(ap + 32 * MLD + (k4 + 1) * 4);
+                fb[nxt][0] = *reinterpret_cast<const float4 *>(wp + (k4 + 1) * 4);
+                fb[nxt][1] = *reinterpret_cast<const float4 *>(wp + 32 * MLD + (k4 + 1) * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 a0 = fa[cur][0], a1 = fa[cur][1], b0 = fb[cur][0], b1 = fb[cur][1];
             {   // k = 4*k4 + h
                 const float fa0 = h ? a0.y : a0.x, fa1 = h ? a1.y : a1.x, fb0 = h ? b0.y : b0.x, fb1 = h ? b1.y : b1.x;
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb0, acc[0][0], 0, 0, 0);
@@ -265,6 +277,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc[1][1], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
