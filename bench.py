@@ -57,7 +57,10 @@ def site_work(site, cfg):
     B, C, Nv, H, E, F, hid, D, n, Nq = (cfg[k] for k in ("Bq", "C", "Nv", "H", "E", "F", "hid", "D", "n", "Nq"))
     M = n * (n + 1) // 2
     table = {
-        "gemm_lstm_rec": 2.0 * 2 * B * 4 * H * (E + H),       # fused step: [x_t | h] x [Wih | Whh]^T, both directions
+        # fused step [x_t | h] x [Wih | Whh]^T; rows actually processed per launch, averaged over the T steps: the
+        # forward direction steps every query (+1 all-pad row), the reverse direction only the queries that have
+        # reached a real token (their trailing-pad prefix is shared through the all-pad row)
+        "gemm_lstm_rec": 2.0 * cfg["lstm_rows_per_step"] * 4 * H * (E + H),
         "gemm_lstm_in": 2.0 * 2 * B * 4 * H * E,
         "gemm_vis_seg": 2.0 * C * hid * F,
         "gemm_vis_ctx": 2.0 * Nv * hid * F,
@@ -199,8 +202,13 @@ def main():
     ms_step = dt * 1e3 / args.steps
     value = Nq * Nv / (dt / args.steps)
     n_eff = float(np.mean(counts_all))
-    cfg = dict(Bq=-(-Nq // world), C=C_loc, Nv=hi - lo, H=model.hidden_size, E=100, F=F, hid=500, D=100,
-               n=int(round(n_eff)), Nq=Nq, T=tokens.shape[1])
+    Bq = -(-Nq // world)
+    tok0 = synth.query_tokens(Nq, seed=123)[:Bq]                       # rank 0's query slice (host copy of the tokens)
+    T_ = tok0.shape[1]
+    qlen = np.where(tok0 != 0, np.arange(1, T_ + 1)[None, :], 0).max(axis=1)
+    rev_rows = sum(1 + int((qlen > T_ - 1 - s).sum()) for s in range(T_)) / T_
+    cfg = dict(Bq=Bq, C=C_loc, Nv=hi - lo, H=model.hidden_size, E=100, F=F, hid=500, D=100,
+               n=int(round(n_eff)), Nq=Nq, T=T_, lstm_rows_per_step=(Bq + 1) + rev_rows)
     kernels, dom, dom_ms = {}, None, -1.0
     for name, (ms, cnt) in sites.items():
         fl = site_work(name, cfg)

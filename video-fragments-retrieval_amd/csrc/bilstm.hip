@@ -58,21 +58,89 @@ __global__ __launch_bounds__(256) void lstm_pointwise_kernel(const float *__rest
     hcat[b * 2 * H + (int64_t)d * H + j] = og * c_tanhf(cn);
 }
 
+// ---- row bookkeeping for the fused path --------------------------------------------------------------------------
+// Trailing pads: in the REVERSE direction a query first consumes its trailing pad tokens starting from the zero state,
+// so during that prefix its (h, c) depends only on the number of pad steps -- it is the state of an all-pad query.
+// That evolution is computed once (GEMM row 0 = a virtual all-pad query); queries are sorted by length (descending)
+// so the rows that have reached a real token form a prefix, and a query joins at its last real token with row 0's
+// state.  Each row's arithmetic is unchanged, so the result is bit-identical to stepping every query through its pads.
+__global__ __launch_bounds__(256) void query_length_kernel(const int64_t *__restrict__ tokens, int64_t B, int T,
+                                                           int *__restrict__ len)
+{
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int l = 0;
+    for (int t = 0; t < T; ++t)
+        if (tokens[b * T + t] != 0) l = t + 1;          // position of the last non-pad token + 1
+    len[b] = l;
+}
+
+// stable descending-length order: GEMM row m = 1 + (#queries longer than b) + (#earlier queries of the same length);
+// row 0 is the virtual all-pad query (index B in the extended token array)
+__global__ __launch_bounds__(256) void sort_rows_kernel(const int *__restrict__ len, int64_t B, int *__restrict__ row_of,
+                                                        int *__restrict__ xrow)
+{
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) xrow[0] = (int)B;
+    if (b >= B) return;
+    const int lb = len[b];
+    int pos = 0;
+    for (int64_t o = 0; o < B; ++o) {
+        const int lo = len[o];
+        pos += (lo > lb || (lo == lb && o < b)) ? 1 : 0;
+    }
+    row_of[b] = pos + 1;
+    xrow[pos + 1] = (int)b;
+}
+
+// mcount[s] = 1 + #{b : len[b] > T-1-s}: active rows of the reverse direction at step s
+__global__ void active_rows_kernel(const int *__restrict__ len, int64_t B, int T, int *__restrict__ mcount)
+{
+    const int s = threadIdx.x;
+    if (s >= T) return;
+    int c = 1;
+    for (int64_t b = 0; b < B; ++b) c += len[b] > T - 1 - s ? 1 : 0;
+    mcount[s] = c;
+}
+
+// [B+1 sorted rows, 2H] -> [B, 2H] in query order; an all-pad query's reverse half is the pad row's
+__global__ __launch_bounds__(256) void unsort_rows_kernel(const float *__restrict__ hs, const int *__restrict__ row_of,
+                                                          const int *__restrict__ len, int64_t B, int H,
+                                                          float *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 2 * H) return;
+    const int64_t b = i / (2 * H);
+    const int j = (int)(i - b * 2 * H);
+    const int64_t src = (len && j >= H && len[b] == 0) ? 0 : (row_of ? (int64_t)row_of[b] : b);
+    out[i] = hs[src * 2 * H + j];
+}
+
 struct LstmWs {
-    float *X, *gates, *c, *hcat, *hcat2;
+    float *X, *gates, *c, *c2, *hcat, *hcat2, *hfinal;
+    int64_t *tok_ext;
+    int *len, *row_of, *xrow, *mcount;
     size_t total;
 };
 static LstmWs carve(void *base, int64_t B, int T, int E, int H)
 {
     LstmWs w{};
     size_t off = 0;
-    auto take = [&](size_t n) { float *p = reinterpret_cast<float *>(static_cast<char *>(base) + off);
-                                off += align_up(n * sizeof(float), 256); return p; };
-    w.X = take((size_t)B * T * E);
-    w.gates = take((size_t)2 * B * 4 * H);
-    w.c = take((size_t)2 * B * H);
-    w.hcat = take((size_t)B * 2 * H);
-    w.hcat2 = take((size_t)B * 2 * H);      // h ping-pong for the fused step kernel
+    auto take_b = [&](size_t bytes) { char *p = static_cast<char *>(base) + off; off += align_up(bytes, 256); return p; };
+    auto take = [&](size_t n) { return reinterpret_cast<float *>(take_b(n * sizeof(float))); };
+    const size_t R = (size_t)B + 1;                       // + the virtual all-pad query
+    w.X = take(R * T * E);
+    w.gates = take((size_t)2 * R * 4 * H);
+    w.c = take((size_t)2 * R * H);
+    w.c2 = take((size_t)2 * R * H);
+    w.hcat = take(R * 2 * H);
+    w.hcat2 = take(R * 2 * H);
+    w.hfinal = take((size_t)B * 2 * H);
+    w.tok_ext = reinterpret_cast<int64_t *>(take_b(R * T * sizeof(int64_t)));
+    w.len = reinterpret_cast<int *>(take_b(R * sizeof(int)));
+    w.row_of = reinterpret_cast<int *>(take_b(R * sizeof(int)));
+    w.xrow = reinterpret_cast<int *>(take_b(R * sizeof(int)));
+    w.mcount = reinterpret_cast<int *>(take_b((size_t)(T + 1) * sizeof(int)));
     w.total = off;
     return w;
 }
@@ -106,44 +174,59 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
     const float *bih[2] = {bih_f, bih_b}, *bhh[2] = {bhh_f, bhh_b};
     const int G = 4 * H;
 
+    VFR_REQUIRE(T <= 1024, VFR_EUNSUPPORTED, "vfr_bilstm_final_f32: T=%d > 1024", T);
+    const int64_t R = B + 1;                                // GEMM rows: row 0 = all-pad query, then queries by length
+    // tokens + one all-pad query -> embeddings of R queries
+    if (hipMemcpyAsync(w.tok_ext, tokens, (size_t)B * T * sizeof(int64_t), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemsetAsync(w.tok_ext + (size_t)B * T, 0, (size_t)T * sizeof(int64_t), st) != hipSuccess ||
+        hipMemsetAsync(w.c, 0, (size_t)2 * R * H * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(w.hcat, 0, (size_t)R * 2 * H * sizeof(float), st) != hipSuccess)
+        return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: buffer initialisation failed");
     {
     vfr::ProfScope prof(vfr::SITE_EMBED, st);
-    hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(B * T, 256)), dim3(256), 0, st, tokens, B * T, vocab,
+    hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(R * T, 256)), dim3(256), 0, st, w.tok_ext, R * T, vocab,
                        emb, len_tab, E, w.X);
+    hipLaunchKernelGGL(vfr::query_length_kernel, dim3((unsigned)vfr::cdiv(B, 256)), dim3(256), 0, st, tokens, B, T, w.len);
+    hipLaunchKernelGGL(vfr::sort_rows_kernel, dim3((unsigned)vfr::cdiv(B, 256)), dim3(256), 0, st, w.len, B, w.row_of, w.xrow);
+    hipLaunchKernelGGL(vfr::active_rows_kernel, dim3(1), dim3(T < 64 ? 64 : T), 0, st, w.len, B, T, w.mcount);
     }
-    VFR_CHECK_LAUNCH("embed_kernel");
-    if (hipMemsetAsync(w.c, 0, (size_t)2 * B * H * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(w.hcat, 0, (size_t)B * 2 * H * sizeof(float), st) != hipSuccess)
-        return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: hipMemsetAsync failed");
-    float *h_final = w.hcat;
+    VFR_CHECK_LAUNCH("bilstm row bookkeeping");
+    float *h_sorted = w.hcat;
     const bool fused = vfr::opt_gemm() != 0 && (E % 4) == 0 && (H % 4) == 0 &&
                        ((((uintptr_t)Wih_f) | ((uintptr_t)Whh_f) | ((uintptr_t)Wih_b) | ((uintptr_t)Whh_b)) & 15) == 0;
     if (fused) {
-        // one MFMA launch per time step for both directions: K = [x_t (E) | h (H)], gate epilogue fused
-        float *hin = w.hcat, *hout = w.hcat2;
+        // one MFMA launch per time step for both directions: K = [x_t (E) | h (H)], gate epilogue fused; the reverse
+        // direction only touches the rows that have reached a real token (lstm_mcount), the rest ride on row 0
+        float *hin = w.hcat, *hout = w.hcat2, *cin = w.c, *cout = w.c2;
         for (int step = 0; step < T; ++step) {
             vfr::GemmArgs g[2]{};
             for (int d = 0; d < 2; ++d) {
                 const int t = d ? T - 1 - step : step;
                 g[d].A = w.X + (size_t)t * E; g[d].lda = (int64_t)T * E; g[d].W = Wih[d]; g[d].ldw = E; g[d].K = E;
                 g[d].A2 = hin + (size_t)d * H; g[d].lda2 = 2 * H; g[d].W2 = Whh[d]; g[d].ldw2 = H; g[d].K2 = H;
-                g[d].bias = bih[d]; g[d].bias2 = bhh[d]; g[d].M = B; g[d].N = G;
-                g[d].lstm_c = w.c + (size_t)d * B * H; g[d].lstm_h = hout + (size_t)d * H; g[d].lstm_ldh = 2 * H;
+                g[d].bias = bih[d]; g[d].bias2 = bhh[d]; g[d].M = R; g[d].N = G;
+                g[d].lstm_c = cout + (size_t)d * R * H; g[d].lstm_cin = cin + (size_t)d * R * H;
+                g[d].lstm_h = hout + (size_t)d * H; g[d].lstm_ldh = 2 * H;
                 g[d].lstm_H = H; g[d].out = hout; g[d].site = vfr::SITE_GEMM_LSTM_REC;
+                g[d].lstm_xrow = w.xrow; g[d].lstm_mcount = d ? w.mcount : nullptr; g[d].lstm_step = step;
             }
             if (int rc = vfr::lstm_step_pair(g[0], g[1], st)) return rc;
+            // reverse-direction rows that have not joined yet keep (unused) stale values in the ping-pong buffers; they
+            // are overwritten from row 0 when they join, so nothing needs copying between the buffers
             float *tmp = hin; hin = hout; hout = tmp;
+            tmp = cin; cin = cout; cout = tmp;
         }
-        h_final = hin;
+        h_sorted = hin;
     } else {
-        // generic path (any E/H alignment, or the VALU cross-check build): same canonical order, unfused --
-        // x-part chain into gates, h-part chain continuing from it (C-in), then the pointwise kernel adds the biases
+        // generic path (any E/H alignment, or the VALU cross-check build): same canonical order, unfused and without
+        // the pad-prefix sharing -- x-part chain into gates, h-part chain continuing from it (C-in), then the pointwise
+        // kernel adds the biases.  Rows stay in query order (row B is the unused all-pad query).
         for (int step = 0; step < T; ++step) {
             vfr::GemmArgs gx[2]{}, gh[2]{};
             for (int d = 0; d < 2; ++d) {
                 const int t = d ? T - 1 - step : step;
                 gx[d].A = w.X + (size_t)t * E; gx[d].lda = (int64_t)T * E; gx[d].W = Wih[d]; gx[d].ldw = E;
-                gx[d].out = w.gates + (size_t)d * B * G; gx[d].ldo = G; gx[d].M = B; gx[d].N = G; gx[d].K = E;
+                gx[d].out = w.gates + (size_t)d * R * G; gx[d].ldo = G; gx[d].M = R; gx[d].N = G; gx[d].K = E;
                 gx[d].site = vfr::SITE_GEMM_LSTM_IN;
                 gh[d] = gx[d];
                 gh[d].A = w.hcat + (size_t)d * H; gh[d].lda = 2 * H; gh[d].W = Whh[d]; gh[d].ldw = H; gh[d].K = H;
@@ -153,12 +236,16 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
             if (int rc = vfr::gemm_nt_pair(gh[0], gh[1], st)) return rc;
             {
             vfr::ProfScope prof(vfr::SITE_LSTM_POINTWISE, st);
-            hipLaunchKernelGGL(vfr::lstm_pointwise_kernel, dim3((unsigned)vfr::cdiv(2 * B * H, 256)), dim3(256), 0, st,
-                               w.gates, bih_f, bhh_f, bih_b, bhh_b, w.c, w.hcat, B, H);
+            hipLaunchKernelGGL(vfr::lstm_pointwise_kernel, dim3((unsigned)vfr::cdiv(2 * R * H, 256)), dim3(256), 0, st,
+                               w.gates, bih_f, bhh_f, bih_b, bhh_b, w.c, w.hcat, R, H);
             }
             VFR_CHECK_LAUNCH("lstm_pointwise_kernel");
         }
     }
+    float *h_final = w.hfinal;
+    hipLaunchKernelGGL(vfr::unsort_rows_kernel, dim3((unsigned)vfr::cdiv(B * 2 * H, 256)), dim3(256), 0, st, h_sorted,
+                       fused ? w.row_of : nullptr, fused ? w.len : nullptr, B, H, h_final);
+    VFR_CHECK_LAUNCH("unsort_rows_kernel");
     vfr::GemmArgs g{};
     g.A = h_final; g.lda = 2 * H; g.W = Wfc; g.ldw = 2 * H; g.out = out; g.ldo = D; g.M = B; g.N = D; g.K = 2 * H;
     g.bias = bfc; g.epi = vfr::EPI_BIAS; g.site = vfr::SITE_GEMM_LANG_FC;

@@ -123,6 +123,10 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * MBM;
     const int n0 = blockIdx.y * MBN;
+    // LSTM step with a shrinking / growing active prefix: rows past the active count do nothing this step
+    const int64_t Mrows = (LSTM && g.lstm_mcount) ? (int64_t)g.lstm_mcount[g.lstm_step] : g.M;
+    const int64_t Mprev = (LSTM && g.lstm_mcount) ? (g.lstm_step > 0 ? (int64_t)g.lstm_mcount[g.lstm_step - 1] : 1) : Mrows;
+    if (LSTM && m0 >= Mrows) return;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -144,17 +148,18 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
-        const int64_t ma = m0 + row < g.M ? m0 + row : g.M - 1;
+        const int64_t ma = m0 + row < Mrows ? m0 + row : Mrows - 1;
         int64_t nw = (int64_t)n0 + row < g.N ? (int64_t)n0 + row : g.N - 1;
         if (LSTM) {   // tile row R = (wn, ni, l31): gate = 2*ni + (l31 >> 4), unit = 32*blockIdx.y + 16*wn + (l31 & 15)
             const int gate = ((row >> 5) & 1) * 2 + ((row >> 4) & 1);
             int unit = blockIdx.y * 32 + (row >> 6) * 16 + (row & 15);
             unit = unit < g.lstm_H ? unit : g.lstm_H - 1;
             nw = (int64_t)gate * g.lstm_H + unit;
-            arow2[i] = g.A2 + ma * g.lda2 + kk;
+            const int64_t hsrc = ma >= Mprev ? 0 : ma;             // a row joining now continues from the pad row's state
+            arow2[i] = g.A2 + hsrc * g.lda2 + kk;
             wrow2[i] = g.W2 + nw * g.ldw2 + kk;
         }
-        arow[i] = CONV ? g.A : g.A + ma * g.lda + kk;
+        arow[i] = CONV ? g.A : g.A + ((LSTM && g.lstm_xrow) ? (int64_t)g.lstm_xrow[ma] : ma) * g.lda + kk;
         wrow[i] = g.W + nw * g.ldw + kk;
     }
     auto gload_full = [&](int k0) {
@@ -324,14 +329,14 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 const float p1 = __shfl_xor(acc[mi][1][r], 16, 64);      // partner's tile-1 gate (o for low, g for high)
                 const bool mine = ((r & 1) != 0) == hi_lane;
                 const int64_t row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (mine && valid && row < g.M) {
+                if (mine && valid && row < Mrows) {
                     const float xi = hi_lane ? p0 : acc[mi][0][r], xf = hi_lane ? acc[mi][0][r] : p0;
                     const float xg = hi_lane ? p1 : acc[mi][1][r], xo = hi_lane ? acc[mi][1][r] : p1;
                     const float ig = c_sigmoidf(xi + bi);
                     const float fg = c_sigmoidf(xf + bf);
                     const float gg = c_tanhf(xg + bg);
                     const float og = c_sigmoidf(xo + bo);
-                    const float cn = __builtin_fmaf(fg, g.lstm_c[row * H + unit], ig * gg);
+                    const float cn = __builtin_fmaf(fg, g.lstm_cin[(row >= Mprev ? 0 : row) * H + unit], ig * gg);
                     g.lstm_c[row * H + unit] = cn;
                     g.lstm_h[row * g.lstm_ldh + unit] = og * c_tanhf(cn);
                 }
@@ -397,7 +402,7 @@ int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
 {
     if (g0.M == 0) return VFR_OK;
     for (const GemmArgs *g : {&g0, &g1}) {
-        VFR_REQUIRE(g->A && g->W && g->A2 && g->W2 && g->bias && g->bias2 && g->lstm_c && g->lstm_h && g->lstm_H > 0, VFR_EINVAL,
+        VFR_REQUIRE(g->A && g->W && g->A2 && g->W2 && g->bias && g->bias2 && g->lstm_c && g->lstm_cin && g->lstm_h && g->lstm_H > 0, VFR_EINVAL,
                     "lstm_step_pair: bad argument");
         VFR_REQUIRE(((g->lda | g->ldw | g->lda2 | g->ldw2 | g->K | g->K2) & 3) == 0 &&
                         ((((uintptr_t)g->A) | ((uintptr_t)g->W) | ((uintptr_t)g->A2) | ((uintptr_t)g->W2)) & 15) == 0,

@@ -80,6 +80,11 @@ struct GemmArgs {
     // N (grid) = lstm_H hidden units, bias / bias2 are the [4H] b_ih / b_hh.
     const float *A2; int64_t lda2; const float *W2; int64_t ldw2; int K2;
     float *lstm_c; float *lstm_h; int64_t lstm_ldh; int lstm_H;
+    const float *lstm_cin;             // previous cell state (c is ping-ponged like h: a joining row reads row 0's OLD state)
+    // row bookkeeping of the fused step (all nullable): lstm_xrow[m] = query whose tokens feed GEMM row m;
+    // lstm_mcount[s] = number of active rows at step s (rows are sorted so the active set is a prefix); rows that join
+    // at step s (>= lstm_mcount[s-1], or >= 1 at s = 0) take their incoming state from row 0, the all-pad row.
+    const int *lstm_xrow; const int *lstm_mcount; int lstm_step;
 };
 int gemm_nt(const GemmArgs &g, hipStream_t st);
 // two GEMMs of identical shape as ONE grid (blockIdx.z picks the problem): fills the chip when one alone leaves a
