@@ -76,19 +76,35 @@ __global__ __launch_bounds__(256) void query_length_kernel(const int64_t *__rest
 }
 
 // stable descending-length order: GEMM row m = 1 + (#queries longer than b) + (#earlier queries of the same length);
-// row 0 is the virtual all-pad query (index B in the extended token array)
-__global__ __launch_bounds__(256) void sort_rows_kernel(const int *__restrict__ len, int64_t B, int *__restrict__ row_of,
-                                                        int *__restrict__ xrow)
+// row 0 is the virtual all-pad query (index B in the extended token array).  Two small kernels: per-block length
+// histograms, then every query sums the bins above it, the earlier blocks' bin and its in-block predecessors.
+constexpr int SORT_BLOCK = 256, SORT_BINS = 1025;          // lengths 0..T, T <= 1024
+__global__ __launch_bounds__(SORT_BLOCK) void length_hist_kernel(const int *__restrict__ len, int64_t B, int T,
+                                                                 int *__restrict__ hist /*[blocks][T+1]*/)
 {
-    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int h[SORT_BINS];
+    for (int i = threadIdx.x; i <= T; i += SORT_BLOCK) h[i] = 0;
+    __syncthreads();
+    const int64_t b = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x;
+    if (b < B) atomicAdd(&h[len[b]], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i <= T; i += SORT_BLOCK) hist[(size_t)blockIdx.x * (T + 1) + i] = h[i];
+}
+__global__ __launch_bounds__(SORT_BLOCK) void sort_rows_kernel(const int *__restrict__ len, const int *__restrict__ hist,
+                                                               int64_t B, int T, int *__restrict__ row_of,
+                                                               int *__restrict__ xrow)
+{
+    const int64_t b = (int64_t)blockIdx.x * SORT_BLOCK + threadIdx.x;
     if (b == 0) xrow[0] = (int)B;
     if (b >= B) return;
-    const int lb = len[b];
+    const int lb = len[b], nblk = (int)((B + SORT_BLOCK - 1) / SORT_BLOCK);
     int pos = 0;
-    for (int64_t o = 0; o < B; ++o) {
-        const int lo = len[o];
-        pos += (lo > lb || (lo == lb && o < b)) ? 1 : 0;
+    for (int k = 0; k < nblk; ++k) {
+        const int *hk = hist + (size_t)k * (T + 1);
+        for (int l = lb + 1; l <= T; ++l) pos += hk[l];              // every longer query, any block
+        if (k < (int)blockIdx.x) pos += hk[lb];                      // same length, earlier block
     }
+    for (int64_t o = (int64_t)blockIdx.x * SORT_BLOCK; o < b; ++o) pos += len[o] == lb ? 1 : 0;   // same length, same block
     row_of[b] = pos + 1;
     xrow[pos + 1] = (int)b;
 }
@@ -119,7 +135,7 @@ __global__ __launch_bounds__(256) void unsort_rows_kernel(const float *__restric
 struct LstmWs {
     float *X, *gates, *c, *c2, *hcat, *hcat2, *hfinal;
     int64_t *tok_ext;
-    int *len, *row_of, *xrow, *mcount;
+    int *len, *row_of, *xrow, *mcount, *hist;
     size_t total;
 };
 static LstmWs carve(void *base, int64_t B, int T, int E, int H)
@@ -141,6 +157,7 @@ static LstmWs carve(void *base, int64_t B, int T, int E, int H)
     w.row_of = reinterpret_cast<int *>(take_b(R * sizeof(int)));
     w.xrow = reinterpret_cast<int *>(take_b(R * sizeof(int)));
     w.mcount = reinterpret_cast<int *>(take_b((size_t)(T + 1) * sizeof(int)));
+    w.hist = reinterpret_cast<int *>(take_b((size_t)cdiv(R, SORT_BLOCK) * (T + 1) * sizeof(int)));
     w.total = off;
     return w;
 }
@@ -187,7 +204,10 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
     hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(R * T, 256)), dim3(256), 0, st, w.tok_ext, R * T, vocab,
                        emb, len_tab, E, w.X);
     hipLaunchKernelGGL(vfr::query_length_kernel, dim3((unsigned)vfr::cdiv(B, 256)), dim3(256), 0, st, tokens, B, T, w.len);
-    hipLaunchKernelGGL(vfr::sort_rows_kernel, dim3((unsigned)vfr::cdiv(B, 256)), dim3(256), 0, st, w.len, B, w.row_of, w.xrow);
+    hipLaunchKernelGGL(vfr::length_hist_kernel, dim3((unsigned)vfr::cdiv(B, vfr::SORT_BLOCK)), dim3(vfr::SORT_BLOCK), 0, st,
+                       w.len, B, T, w.hist);
+    hipLaunchKernelGGL(vfr::sort_rows_kernel, dim3((unsigned)vfr::cdiv(B, vfr::SORT_BLOCK)), dim3(vfr::SORT_BLOCK), 0, st,
+                       w.len, w.hist, B, T, w.row_of, w.xrow);
     hipLaunchKernelGGL(vfr::active_rows_kernel, dim3(1), dim3(T < 64 ? 64 : T), 0, st, w.len, B, T, w.mcount);
     }
     VFR_CHECK_LAUNCH("bilstm row bookkeeping");
