@@ -75,6 +75,82 @@ __global__ __launch_bounds__(256) void segment_pool_norm_kernel(const float *__r
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Single-pass form for batches (F <= 4096): one 1024-thread workgroup per video, thread = one float4 column chunk.
+// Every frame element is read ONCE: the same load feeds the running segment pool and the whole-video (context)
+// pool, both in frame order (the canonical sums).  At a segment end the row's sum of squares is taken with the
+// oracle's R3 tree through LDS: lane l of wave 0 chains the chunks l, l+64, ... in order, then the xor butterfly.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row_norm_tree64(float4 v, int chunk, int nchunk, float4 *sh, float *sh_norm)
+{
+    __syncthreads();                                   // previous use of sh / sh_norm finished
+    if (chunk < nchunk) sh[chunk] = v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float ss = 0.0f;
+        for (int c = threadIdx.x; c < nchunk; c += 64) {
+            const float4 a = sh[c];
+            ss = __builtin_fmaf(a.x, a.x, ss);
+            ss = __builtin_fmaf(a.y, a.y, ss);
+            ss = __builtin_fmaf(a.z, a.z, ss);
+            ss = __builtin_fmaf(a.w, a.w, ss);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ss = ss + __shfl_xor(ss, off, 64);
+        if (threadIdx.x == 0) *sh_norm = __builtin_sqrtf(ss) + 1e-5f;
+    }
+    __syncthreads();
+    return *sh_norm;
+}
+
+__global__ __launch_bounds__(1024) void segment_pool_norm_video_kernel(const float *__restrict__ frames,
+                                                                      const int32_t *__restrict__ frame_off,
+                                                                      const int32_t *__restrict__ seg_off, int F,
+                                                                      int seg_len, int mode, float *__restrict__ seg,
+                                                                      float *__restrict__ ctx)
+{
+    __shared__ float4 sh[1024];
+    __shared__ float sh_norm;
+    const int v = blockIdx.x, chunk = threadIdx.x, nchunk = F >> 2;
+    const bool live = chunk < nchunk;
+    const int64_t fbeg = frame_off[v], fend = frame_off[v + 1];
+    int64_t srow = seg_off[v];
+    const float4 *src = reinterpret_cast<const float4 *>(frames) + fbeg * nchunk + (live ? chunk : 0);
+    float4 call = make_float4(0.f, 0.f, 0.f, 0.f), cseg = call;
+    int in_seg = 0;
+    for (int64_t t = fbeg; t < fend; ++t, src += nchunk) {
+        const float4 x = live ? *src : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t == fbeg) call = x;
+        else if (mode) { call.x = fmaxf(call.x, x.x); call.y = fmaxf(call.y, x.y); call.z = fmaxf(call.z, x.z); call.w = fmaxf(call.w, x.w); }
+        else { call.x = call.x + x.x; call.y = call.y + x.y; call.z = call.z + x.z; call.w = call.w + x.w; }
+        if (in_seg == 0) cseg = x;
+        else if (mode) { cseg.x = fmaxf(cseg.x, x.x); cseg.y = fmaxf(cseg.y, x.y); cseg.z = fmaxf(cseg.z, x.z); cseg.w = fmaxf(cseg.w, x.w); }
+        else { cseg.x = cseg.x + x.x; cseg.y = cseg.y + x.y; cseg.z = cseg.z + x.z; cseg.w = cseg.w + x.w; }
+        ++in_seg;
+        if (in_seg == seg_len || t + 1 == fend) {       // segment complete (uniform across the workgroup)
+            if (!mode) { const float c = (float)in_seg; cseg.x = cseg.x / c; cseg.y = cseg.y / c; cseg.z = cseg.z / c; cseg.w = cseg.w / c; }
+            const float nrm = row_norm_tree64(cseg, chunk, nchunk, sh, &sh_norm);
+            if (live) {
+                float4 o;
+                o.x = cseg.x / nrm; o.y = cseg.y / nrm; o.z = cseg.z / nrm; o.w = cseg.w / nrm;
+                reinterpret_cast<float4 *>(seg + srow * F)[chunk] = o;
+            }
+            ++srow;
+            in_seg = 0;
+        }
+    }
+    if (fend > fbeg) {
+        if (!mode) { const float c = (float)(fend - fbeg); call.x = call.x / c; call.y = call.y / c; call.z = call.z / c; call.w = call.w / c; }
+        const float nrm = row_norm_tree64(call, chunk, nchunk, sh, &sh_norm);
+        if (live) {
+            float4 o;
+            o.x = call.x / nrm; o.y = call.y / nrm; o.z = call.z / nrm; o.w = call.w / nrm;
+            reinterpret_cast<float4 *>(ctx + (int64_t)v * F)[chunk] = o;
+        }
+    }
+}
+
 static int launch_pool(const float *frames, const int32_t *frame_off, const int32_t *seg_off, int Nv, int64_t rows,
                        int F, int seg_len, int mode, int single_T, float *seg, float *ctx, hipStream_t st)
 {
@@ -109,6 +185,13 @@ int vfr_segment_pool_norm_batch_f32(const float *frames, const int32_t *frame_of
                     seg_len > 0 && (mode == 0 || mode == 1),
                 VFR_EINVAL, "vfr_segment_pool_norm_batch_f32: bad argument");
     if (Nv == 0) return VFR_OK;
+    if (F <= 4096 && (F & 3) == 0 && ((((uintptr_t)frames | (uintptr_t)seg | (uintptr_t)ctx) & 15) == 0)) {
+        vfr::ProfScope prof(vfr::SITE_POOL, vfr::as_stream(stream));
+        hipLaunchKernelGGL(vfr::segment_pool_norm_video_kernel, dim3((unsigned)Nv), dim3(1024), 0, vfr::as_stream(stream),
+                           frames, frame_offsets, seg_offsets, F, seg_len, mode, seg, ctx);
+        VFR_CHECK_LAUNCH("segment_pool_norm_video_kernel");
+        return VFR_OK;
+    }
     return vfr::launch_pool(frames, frame_offsets, seg_offsets, Nv, (int64_t)total_segments + Nv, F, seg_len, mode, 0,
                             seg, ctx, vfr::as_stream(stream));
 }
