@@ -341,3 +341,66 @@ def test_full_size_properties(vfr):
         sub = vfr.VideoBank(V[v * n:(v + 1) * n].contiguous(), off[:2].contiguous(), int(v) * M)
         dense = vfr.score_moments(Q[q:q + 1].contiguous(), sub)
         assert float(dense.min()) == float(d[q, 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,clips", [("n6", 6), ("ragged", "didemo")])
+@pytest.mark.parametrize("size", [25, -1])
+def test_validate_epoch_on_gpu_matches_reference_scalars(vfr, tag, clips, size):
+    """Trainer.validate_epoch (main.py:121-212) through the fused kernels == the scalars the reference logged."""
+    from vfr_amd import evaluate as vevaluate
+    from test_host_logic import _check_validate
+    ref = json.load(open(Path(__file__).parent / "golden" / "g6_validate_epoch.json"))[f"{tag}_size{size}"]
+    p = problem(60, 40, clips, seed=77)
+    ds = MemoryDataset(p["seg"], p["ctx"], p["counts"], p["tokens"], p["own"], p["times"])
+    vi, li = ds.iterators()
+    got = vevaluate.validate_epoch(make_model(p["sd"]).to(DEV), vi, li, ds.annotations, DEV, size=size)
+    _check_validate(got, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["avg", "max"])
+def test_file_dataset_pools_on_gpu_and_evaluates(vfr, oracle, golden, mode, tmp_path):
+    """data.CustomDataset over .npy frame features (model/data.py:163-188) with the pooling done by the per-video HIP
+    kernel: pooled features == oracle bits and == the reference's arrays (g4); then the full evaluate() from files."""
+    from vfr_amd import data as vdata
+    from vfr_amd import evaluate as vevaluate
+    g = golden("g4_pooling.npz")
+    d = tmp_path / "features_vgg19"
+    d.mkdir()
+    lengths, names = (150, 138, 125, 112), []
+    for T in lengths:
+        x = np.random.RandomState(1000 + T).rand(T, 4096).astype(np.float32)
+        x[x < 0.3] = 0.0
+        np.save(d / f"vgg19_ft_vid{T}.npy", x)
+        names.append(f"vid{T}")
+    sd = synth.model_weights(4096, seed=5)
+    words = [f"w{i}" for i in range(1, 60)]
+    with open(tmp_path / "glove.6B.100d.txt", "w") as fh:                    # a tiny GloVe file: 59 words + unk
+        for w in words + ["unk"]:
+            fh.write(w + " " + " ".join(["0.5"] * 100) + "\n")
+    wi = vdata.WordIndexer(str(tmp_path))
+    rs = np.random.RandomState(3)
+    annots = {q: dict(video=names[q % 4], description=" ".join(rs.choice(words, size=rs.randint(1, 25))),
+                      times=[[0, 0], [0, 1], [0, 0], [1, 1]]) for q in range(12)}
+    ds = vdata.CustomDataset(names, annots, str(tmp_path), "vgg19", word_indexer=wi, validate=True, pooling=mode,
+                             pool_device="cuda")
+    for T, name in zip(lengths, names):
+        x = np.load(d / f"vgg19_ft_{name}.npy")
+        oseg, octx = oracle.segment_pool_norm(x, 25, mode)
+        vf = ds.video_features[name]
+        assert vf["num_segments"] == int(g[f"nseg_{mode}_{T}"])
+        assert np.array_equal(vf["segment_features"].astype(np.float32), oseg) and np.array_equal(vf["context_features"], octx)
+        np.testing.assert_allclose(vf["segment_features"], g[f"seg_{mode}_{T}"], rtol=0, atol=3e-7)
+        np.testing.assert_allclose(vf["context_features"], g[f"ctx_{mode}_{T}"], rtol=0, atol=3e-7)
+
+    def iters():
+        vi = torch.utils.data.DataLoader(ds, shuffle=False, collate_fn=vdata.validate_collate,
+                                         batch_sampler=vdata.VideoBatchSampler(names, ds.num_segments_info))
+        li = torch.utils.data.DataLoader(ds, shuffle=False, collate_fn=vdata.validate_collate,
+                                         batch_sampler=vdata.LanguageBatchSampler(annots, ds.num_segments_info))
+        return vi, li
+    model = make_model(sd)
+    cpu = vevaluate.evaluate(model, *iters(), annots, "cpu")
+    gpu = vevaluate.evaluate(model.to(DEV), *iters(), annots, DEV)
+    assert gpu == cpu

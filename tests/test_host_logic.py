@@ -113,3 +113,26 @@ def test_no_positive_moment_raises_like_reference():
     vi, li = ds.iterators()
     with pytest.raises(IndexError):
         vevaluate.evaluate(make_model(p["sd"]), vi, li, ds.annotations, "cpu")
+
+
+def _check_validate(got, ref):
+    for group in ("CustomRecall", "MedianRank", "MeanReciprocalRank"):
+        assert set(got[group]) == set(ref["scalars"][group]), group
+        for key, want in ref["scalars"][group].items():
+            assert got[group][key] == pytest.approx(want, abs=1e-12), (group, key)
+    assert set(got["pr_curve"]) == set(ref["pr_curve"])
+    for kind, per_k in ref["pr_curve"].items():
+        for k, want in per_k.items():
+            assert got["pr_curve"][kind][int(k)] == pytest.approx(want, abs=1e-12), (kind, k)
+
+
+@pytest.mark.parametrize("tag,clips", [("n6", 6), ("ragged", "didemo")])
+@pytest.mark.parametrize("size", [25, -1])
+def test_validate_epoch_on_cpu_device_matches_reference_scalars(tag, clips, size):
+    """Trainer.validate_epoch (main.py:121-212): `>=` thresholds, 1-based ranks, MRR, size limit, 11-point PR sweep."""
+    ref = json.load(open(Path(__file__).parent / "golden" / "g6_validate_epoch.json"))[f"{tag}_size{size}"]
+    p = problem(60, 40, clips, seed=77)
+    ds = MemoryDataset(p["seg"], p["ctx"], p["counts"], p["tokens"], p["own"], p["times"])
+    vi, li = ds.iterators()
+    got = vevaluate.validate_epoch(make_model(p["sd"]), vi, li, ds.annotations, "cpu", size=size)
+    _check_validate(got, ref)

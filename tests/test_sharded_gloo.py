@@ -34,7 +34,10 @@ def _worker(rank, world, port, clips, out_dir, sample=256):
         vi, li = ds.iterators()
         metrics, (td, ti) = vevaluate.evaluate(model, vi, li, ds.annotations, "cpu", rank=rank, world=world,
                                                return_topk=50)
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), metrics=json.dumps(metrics), td=td.numpy(), ti=ti.numpy())
+        vi, li = ds.iterators()
+        val = vevaluate.validate_epoch(model, vi, li, ds.annotations, "cpu", size=-1, rank=rank, world=world)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), metrics=json.dumps(metrics), td=td.numpy(), ti=ti.numpy(),
+                 val=json.dumps(val))
     finally:
         dist.destroy_process_group()
 
@@ -49,9 +52,12 @@ def test_two_rank_sharded_evaluate_equals_single_process(tmp_path, clips, sample
     vi, li = ds.iterators()
     ref_metrics, (rd, ri) = vevaluate.evaluate(make_model(p["sd"], feat_dim=64, hidden=16), vi, li, ds.annotations,
                                                "cpu", return_topk=50)
+    vi, li = ds.iterators()
+    ref_val = vevaluate.validate_epoch(make_model(p["sd"], feat_dim=64, hidden=16), vi, li, ds.annotations, "cpu", size=-1)
     for r in range(world):
         got = np.load(tmp_path / f"r{r}.npz")
         assert json.loads(str(got["metrics"])) == json.loads(json.dumps(ref_metrics))
+        assert json.loads(str(got["val"])) == json.loads(json.dumps(ref_val))      # 11-threshold sweep, sharded
         assert np.array_equal(got["ti"], ri.numpy())
         assert np.array_equal(got["td"], rd.numpy())
 

@@ -228,6 +228,51 @@ def g5_tokens():
     print("G5", len(sample), "descriptions, vocab", emb.shape)
 
 
+def g6_validate_epoch():
+    """Trainer.validate_epoch (model/main.py:121-212): the third copy of the scoring loop, with `>=` IoU thresholds,
+    1-based ranks and reciprocal rank.  main.py imports tensorboard (absent here) only for SummaryWriter; a recorder
+    stands in for it and captures the scalars the reference logs."""
+    import matplotlib
+    matplotlib.use("Agg")
+    captured = {}
+
+    class Recorder:
+        def __init__(self, *a, **k): pass
+        def add_scalars(self, tag, scalars, global_step=None): captured[tag] = {k: float(v) for k, v in scalars.items()}
+        def add_scalar(self, *a, **k): pass
+        def add_figure(self, *a, **k): pass
+
+    stub = types.ModuleType("torch.utils.tensorboard")
+    stub.SummaryWriter = Recorder
+    sys.modules["torch.utils.tensorboard"] = stub
+    import main as ref_main  # noqa: E402  (reference)
+
+    out = {}
+    for tag, clips in (("n6", 6), ("ragged", "didemo")):
+        nv, nq, feat_dim = 60, 40, 4096
+        counts = synth.clip_counts(nv, clips, seed=77)
+        off = synth.clip_offsets(counts)
+        seg, ctx = synth.video_features(counts, feat_dim, seed=77)
+        tokens = synth.query_tokens(nq, seed=77)
+        own, times = synth.annotations(nq, counts, seed=77)
+        sd = synth.model_weights(feat_dim, seed=77)
+        m = ref_model(sd, feat_dim)
+        ds, videos, annots = make_dataset(seg, ctx, off, tokens, own, times)
+        for size in (25, -1):
+            vi = DataLoader(ds, shuffle=False, collate_fn=ref_data.validate_collate,
+                            batch_sampler=ref_data.VideoBatchSampler(videos, ds.num_segments_info))
+            li = DataLoader(ds, shuffle=False, collate_fn=ref_data.validate_collate,
+                            batch_sampler=ref_data.LanguageBatchSampler(annots, ds.num_segments_info))
+            tr = ref_main.Trainer.__new__(ref_main.Trainer)
+            tr.device, tr.bert, tr.val_writer, tr.global_step = "cpu", False, Recorder(), 0
+            captured.clear()
+            pr = tr.validate_epoch(m, vi, li, annots, size=size)
+            out[f"{tag}_size{size}"] = dict(scalars={k: dict(v) for k, v in captured.items()},
+                                            pr_curve={a: {str(k): [float(x) for x in v] for k, v in b.items()} for a, b in pr.items()})
+    json.dump(out, open(OUT / "g6_validate_epoch.json", "w"))
+    print("G6", {k: v["scalars"].get("MedianRank") for k, v in out.items()})
+
+
 if __name__ == "__main__":
     g3_moments_iou()
     g5_tokens()
@@ -236,3 +281,4 @@ if __name__ == "__main__":
     g2_scoring("n6", 6)
     g2_scoring("ragged", "didemo")
     g2_scoring("n21", 21)
+    g6_validate_epoch()

@@ -216,8 +216,22 @@ def corpus_ranks(shard: CorpusShard, Q, own_global, labels, ops=None, k=0, world
     if bool((keys == KEY_INF).any()):
         raise IndexError("index 0 is out of bounds for axis 0 with size 0 (no ground-truth-positive moment)")
     rank_dist, rank_idx = _unpack_key(keys)
-    od, oi, counts = sharded_search(shard, Q, k, rank_dist.contiguous(), rank_idx.contiguous(), ops, world, workspace)
-    return counts, od, oi
+    R = keys.shape[0]
+    if R == 2:
+        od, oi, counts = sharded_search(shard, Q, k, rank_dist.contiguous(), rank_idx.contiguous(), ops, world, workspace)
+        return counts, od, oi
+    # any other number of thresholds (validate_epoch's 11-point PR sweep, a single threshold): pairs of rank keys,
+    # the shape the fused kernel is instantiated for; an odd tail repeats its last key.  Top-k rides on the first pair.
+    od = oi = None
+    parts = []
+    for r0 in range(0, R, 2):
+        rows = [r0, min(r0 + 1, R - 1)]
+        d, i, c = sharded_search(shard, Q, k if r0 == 0 else 0, rank_dist[rows].contiguous(), rank_idx[rows].contiguous(),
+                                 ops, world, workspace)
+        if r0 == 0:
+            od, oi = d, i
+        parts.append(c[:R - r0])
+    return torch.cat(parts), od, oi
 
 
 def corpus_topk(shard: CorpusShard, Q, k, ops=None, world=1, workspace=None):

@@ -107,3 +107,64 @@ def evaluate(model, video_iterator, lang_iterator, annotations, device, prelimin
     if return_topk:
         return out, (top_dist, top_idx)
     return out
+
+
+def validate_epoch(model, video_iterator, lang_iterator, annotations, device, size=250, iou_thresholds=[0.5, 0.7],
+                   atk=[1, 10, 100], bert=False, rank=0, world=1):
+    """The retrieval metrics of ``Trainer.validate_epoch`` (``model/main.py:121-212``) through the same fused pass.
+
+    Same arguments as the method (minus ``self``; ``device``/``bert`` are the Trainer attributes it reads) and the
+    same numbers, returned instead of written to TensorBoard::
+
+        {"CustomRecall": {"1_IoU05": ..}, "MedianRank": {"IoU05": ..}, "MeanReciprocalRank": {"IoU05": ..},
+         "pr_curve": {"precision": {k: [..11..]}, "recall": {k: [..11..]}}}      # pr_curve == {} unless size == -1
+
+    Semantics that differ from ``evaluate`` and are kept: IoU ``>=`` threshold (``:161``), 1-based rank
+    (``:169``), only the first ``size`` queries are scored (``:186``; ``-1`` = all, and then the 11-point threshold
+    sweep with precision/recall@k, ``:137,178-179,200-206``).  A query without a positive moment raises IndexError.
+    """
+    was_training = model.training
+    model.eval()
+    ops = engine.ops_for(device)
+    shard, names = embed_corpus(model, video_iterator, device, ops, rank, world)
+    video_index = {name: i for i, name in enumerate(names)}
+    thr_range = [i / 10 for i in range(11)] if size == -1 else list(iou_thresholds)
+
+    tokens, q_videos, annot_ids = _drain_queries(lang_iterator if size <= 0 else itertools.islice(lang_iterator, size))   # :186 never fires for size <= 0
+    nq = len(tokens)
+    with torch.no_grad():
+        if bert:
+            Q = model(torch.cat(tokens).to(device), False, device, True).contiguous()
+        else:
+            Q = engine.encode_queries(model, torch.cat(tokens), device, ops, rank, world)
+    own = np.asarray([video_index[v] for v in q_videos], np.int64)
+    times = [annotations[a]["times"] for a in annot_ids]
+    labels = engine.gt_label_table(times, shard.counts_all[own], thr_range, strict=False)
+    kmax = max(atk) if size == -1 else 0
+    ranks0, _, top_idx = engine.corpus_ranks(shard, Q, own, labels, ops, k=kmax, world=world)
+    ranks = ranks0.cpu().numpy() + 1                                              # :169  "+ 1"
+    model.train(was_training)
+
+    keep = [r for r, thr in enumerate(thr_range) if thr in iou_thresholds]
+    tag = lambda thr: f"IoU0{round(thr * 10)}"
+    out = {"CustomRecall": {f"{k}_{tag(thr_range[r])}": float(np.mean(ranks[r] <= k)) for r in keep for k in atk},
+           "MedianRank": {tag(thr_range[r]): float(np.median(ranks[r])) for r in keep},
+           "MeanReciprocalRank": {tag(thr_range[r]): float(np.mean(1.0 / ranks[r])) for r in keep},
+           "pr_curve": {}}
+    if size == -1:
+        # positives among the top-k: only moments of the query's own video can be positive (:162-166)
+        top = top_idx.cpu().numpy()                                               # [Nq, kmax] global moment ids, -1 padded
+        base = shard.mom_off_all[own][:, None]
+        local = top - base
+        Mown = (shard.counts_all[own] * (shard.counts_all[own] + 1) // 2)[:, None]
+        inside = (top >= 0) & (local >= 0) & (local < Mown)
+        qsel = np.arange(nq)[:, None]
+        hits = labels[:, qsel, np.where(inside, local, 0)] & inside[None]         # [R, Nq, kmax]
+        relevant = labels.sum(axis=(1, 2))
+        pr = {"precision": {}, "recall": {}}
+        for k in atk:
+            tp = hits[:, :, :k].sum(axis=(1, 2))
+            pr["precision"][k] = [float(t) / (k * nq) for t in tp]
+            pr["recall"][k] = [float(t) / float(rel) for t, rel in zip(tp, relevant)]
+        out["pr_curve"] = pr
+    return out
