@@ -3,6 +3,7 @@ seeded inputs.  Bar: bit-exact (the kernels implement the oracle's canonical fp3
 within 1e-4 / identical top-k against the reference's own golden vectors."""
 import json
 import random
+from pathlib import Path
 
 import numpy as np
 import pytest
