@@ -457,8 +457,9 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
         dl[r] = 0;
 #pragma unroll
         for (int L = 1; L <= NT; ++L) {
-            const unsigned lo = active ? excl_bound(sum_bound<true>(x, L)) : 0u;
-            const unsigned hi = active ? excl_bound(sum_bound<false>(x, L)) : 0u;
+            // never above bits(+inf): a sum that overflowed (or the +inf padding of a short video) is not < any key
+            const unsigned lo = active ? min(excl_bound(sum_bound<true>(x, L)), 0x7F800000u) : 0u;
+            const unsigned hi = active ? min(excl_bound(sum_bound<false>(x, L)), 0x7F800000u) : 0u;
             const unsigned d = hi - lo;
             wide = wide || d > 3u;
             if (LOX_LDS) lox_lds[(r * NT + (L - 1)) * 64 + lane] = lo; else lox[r][L - 1] = lo;
@@ -563,41 +564,73 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
         float d[NT], sums[NT];
 #pragma unroll
         for (int c = 0; c < NT; ++c) d[c] = (EXACT || c < n) ? ds[c * 64 + lane] : __builtin_inff();
-        bool tie = wide;
+        // The triangle is branch-free: per moment one add, and per rank key u = bits(sum) - LOX, whose sign bit IS
+        // "score < key" (both operands <= bits(+inf)), shifted into a per-level bit collector (v_alignbit; one popcount per level).  The top-k filter and the tie test
+        // need only each level's MINIMUM of bits(sum) resp. u (v_min3: half an instruction per moment), folded once per
+        // level into a per-lane level mask resp. a tie counter.  Moments that reach past the video's last clip carry
+        // +inf sums (d[c >= n] = +inf), which no bound admits: no guards.
+        int ties = wide ? 1 : 0;
+        unsigned lvl = 0;                               // bit (NT - L): some moment of length L may enter the top-k
 #pragma unroll
         for (int L = 1; L <= NT; ++L) {
-            unsigned lx[NRR], hx[NRR];
+            static_assert(NT <= 32, "one 32-bit sign collector per level");
+            unsigned lx[NRR], dlt[NRR], umin[NRR], below[NRR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
+                below[r] = 0u;
                 lx[r] = LOX_LDS ? lox_lds[(r * NT + (L - 1)) * 64 + lane] : lox[LOX_LDS ? 0 : r][LOX_LDS ? 0 : L - 1];
-                hx[r] = lx[r] + ((unsigned)(dl[r] >> (2 * (L - 1))) & 3u);
+                dlt[r] = (unsigned)(dl[r] >> (2 * (L - 1))) & 3u;
+                umin[r] = 0xFFFFFFFFu;
             }
+            unsigned tmin = 0xFFFFFFFFu;
 #pragma unroll
             for (int s = 0; s + L <= NT; ++s) {
-                if (EXACT || s + L <= n) {                 // wave-uniform
-                    const float de = d[s + L - 1];
-                    const float sum = L == 1 ? de : sums[s] + de;
-                    sums[s] = sum;
-                    const unsigned sb = __float_as_uint(sum);
-                    if (TOPK) {
-                        if (sb < hix_t[L - 1]) {             // rare after warm-up: exact score, key, append
+                const float de = d[s + L - 1];
+                const float sum = L == 1 ? de : sums[s] + de;
+                sums[s] = sum;
+                const unsigned sb = __float_as_uint(sum);
+                if (TOPK) tmin = sb < tmin ? sb : tmin;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const unsigned u = sb - lx[r];          // both <= 0x7F800000: bit 31 of u IS "bits(sum) < LOX"
+                    below[r] = __builtin_amdgcn_alignbit(below[r], u, 31);   // shift that bit into the level's collector
+                    umin[r] = u < umin[r] ? u : umin[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                nlt[r] += __builtin_popcount(below[r]);
+                ties += umin[r] < dlt[r] ? 1 : 0;           // some LOX <= bits(sum) < HIX: score == key
+            }
+            if (TOPK) { unsigned t; lvl = lvl + lvl + (__builtin_sub_overflow(tmin, hix_t[L - 1], &t) ? 1u : 0u); }
+            // pin this level's results here: without it the rank half is sunk below the later levels and every sum spills
+            if (NR == 2) asm volatile("" : "+v"(nlt[0]), "+v"(nlt[NR > 1 ? 1 : 0]), "+v"(ties), "+v"(lvl));
+            else asm volatile("" : "+v"(ties), "+v"(lvl));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (TOPK && lvl != 0) {
+            // some moment may enter the top-k: re-walk the flagged levels from the LDS distance column -- the same
+            // left-to-right sums -- with the exact score, key and append
+#pragma unroll
+            for (int L = 1; L <= NT; ++L) {
+                if ((lvl >> (NT - L)) & 1u) {
+                    const unsigned hx = hix_t[L - 1];
+#pragma nounroll
+                    for (int s = 0; s + L <= n; ++s) {
+                        float sum = ds[s * 64 + lane];
+#pragma nounroll
+                        for (int e = s + 1; e < s + L; ++e) sum += ds[e * 64 + lane];
+                        if (__float_as_uint(sum) < hx) {
                             const float sc = sum / (float)L;
                             const unsigned id = (unsigned)(a.id_base + mbase + moment_index(n, s, s + L - 1));
                             const unsigned long long key = make_key(sc, id);
                             if (key < thr) { col[(size_t)cnt * 64 + lane] = key; ++cnt; }
                         }
                     }
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        const bool below = sb < lx[r];
-                        nlt[r] += below ? 1 : 0;
-                        tie = tie || ((sb < hx[r]) && !below);
-                    }
                 }
             }
-            // keep the scheduler from hoisting later rows' LDS reads over this one (register pressure -> spills)
-            __builtin_amdgcn_sched_barrier(0);
         }
+        const bool tie = ties != 0;
         if (NR == 0 || __ballot(tie) == 0) continue;
 
         // ---- some lane has score == a rank key: re-walk this video exactly and break the ties by moment id ----
@@ -860,9 +893,7 @@ static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st, int *cap_tr
         kpl = a.k + Msel <= 256 ? 4 : 8;                   // candidate columns hold k kept + one video's worth
         if (cap_transposed && a.k > 0) *cap_transposed = kpl * 64;
         const bool lox_lds = NT > 6 && a.num_rank > 0;
-        // every video has exactly NT clips: no length guards.  (The fused n = 21 top-k + rank instantiation keeps them:
-        // without the guards' scalar branches hipcc's schedule of the straight-line triangle spills ~900 B/lane.)
-        const bool exact = a.min_clips == NT && !(lox_lds && a.k > 0);
+        const bool exact = a.min_clips == NT;              // every video has exactly NT clips: n is a constant
         const int NCg = 3, rows = (NT + NCg - 1) / NCg * NCg;
         const size_t lds = ((size_t)2 * NCg * FAST_D + (size_t)rows * 64 + (lox_lds ? (size_t)a.num_rank * NT * 64 : 0)) * sizeof(float);
         dim3 grid((unsigned)tasks);
