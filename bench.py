@@ -56,6 +56,7 @@ def site_work(site, cfg):
     """Algorithmic FLOP per launch of an instrumented site (SURVEY.md 8d figures), and which roof bounds it."""
     B, C, Nv, H, E, F, hid, D, n, Nq = (cfg[k] for k in ("Bq", "C", "Nv", "H", "E", "F", "hid", "D", "n", "Nq"))
     M = n * (n + 1) // 2
+    pre = (32 + min(1024, Nv // 8)) if Nv >= 1024 else 0     # threshold ladder of the top-k pass (score.hip: PRE_VIDEOS, pre_b_videos)
     table = {
         # fused step [x_t | h] x [Wih | Whh]^T; rows actually processed per launch, averaged over the T steps: the
         # forward direction steps every query (+1 all-pad row), the reverse direction only the queries that have
@@ -67,11 +68,11 @@ def site_work(site, cfg):
         "gemm_vis_out": 2.0 * C * D * hid,
         "gemm_lang_fc": 2.0 * B * D * 2 * H,
         # scoring launches (2nD contraction + n norms + 2M moment means per scoring).  With top-k the
-        # first 256 videos are the threshold sample (pre-pass + a rank-only launch over them); the fused launch
-        # (top-k + rank keys, one distance pass) covers the rest.
-        "score_fused": float(Nq) * max(Nv - 256, 0) * (2 * n * D + n + 2 * M),
-        "score_rank": float(Nq) * min(Nv, 256) * (2 * n * D + n + 2 * M),
-        "score_prepass": float(Nq) * min(Nv, 256) * (2 * n * D + n + 2 * M),
+        # first 32 videos are scored exactly (stage A + a rank-only launch over them), the next Nv/8 (<= 1024) by a
+        # first fused launch whose merged k-th key is the threshold of the main fused launch over the rest.
+        "score_fused": float(Nq) * max(Nv - pre, 0) * (2 * n * D + n + 2 * M),
+        "score_rank": float(Nq) * min(Nv, 32) * (2 * n * D + n + 2 * M),
+        "score_prepass": float(Nq) * pre / 2 * (2 * n * D + n + 2 * M),       # two launches: stage A + stage B, averaged
     }
     return table.get(site)
 

@@ -180,6 +180,11 @@ struct ScoreArgs {
     int min_clips;                                    // smallest clip count in the bank (0 = unknown)
     int v_lo, v_hi;                                   // video range scored by this launch (chunks partition it)
     int force_generic;                                // 1: use score_kernel (cooperative compaction) even if fast applies
+    int prof_site;                                    // profiler site of this launch (0: chosen from the mode)
+    int keep_all;                                     // 1: hand every appended key to the merge (no final per-column cut)
+#ifdef VFR_SCORE_STAMPS
+    unsigned long long *stamps;                       // debug build: per-phase s_memtime totals of the fused kernel
+#endif
 };
 
 // MODE 0: dense scores; MODE 1: fused top-k and/or rank counting
@@ -492,10 +497,25 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
     int buf = 0;
     if (v0 < v1) { gload(clip_off[v0]); swrite(0); }
 
+#ifdef VFR_SCORE_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+#define STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; }
+#else
+#define STAMP(i)
+#endif
+    // per-video offsets off the critical path: analytic when every video has NT clips, else loaded one video ahead
+    int c_cur = v0 < v1 ? clip_off[v0] : 0, c_nxt = (!EXACT && v0 < v1) ? clip_off[v0 + 1] : 0;
+    int64_t m_cur = v0 < v1 ? mom_off[v0] : 0;
     for (int v = v0; v < v1; ++v) {
-        const int c0 = clip_off[v], n = EXACT ? NT : clip_off[v + 1] - c0;
-        const int64_t mbase = mom_off[v];
+        const int c0 = c_cur, n = EXACT ? NT : c_nxt - c_cur;
+        const int64_t mbase = m_cur;
+        if (EXACT) { c_cur += NT; m_cur += NT * (NT + 1) / 2; }
+        else {
+            c_cur = c_nxt;
+            if (v + 1 < v1) { c_nxt = clip_off[v + 2]; m_cur = mom_off[v + 1]; }     // consumed next iteration
+        }
         const int ng = (n + NC - 1) / NC;
+        STAMP(0)
         if (TOPK) {
             // a video can append up to M = n(n+1)/2 keys per lane: make room first (CAP >= k + M by construction)
             if (__ballot(cnt > CAP - n * (n + 1) / 2)) {
@@ -519,6 +539,7 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
                 dirty = false;
             }
         }
+        STAMP(1)
         // ---- clip distances, NC chains at a time, V rows broadcast from the staging buffer ----
 #pragma nounroll
         for (int g = 0; g < ng; ++g) {
@@ -540,6 +561,9 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
 #pragma unroll
                     for (int i = 0; i < NC; ++i) nxt[i] = vt[i * ROW4 + j4 + 1];
                 }
+                // ONE wait per slice (LDS returns in order: all but the NC reads just issued have landed) instead of one
+                // per clip: every instruction costs the wave an issue slot here
+                if (j4 + 1 < ROW4) __builtin_amdgcn_s_waitcnt(0xC07F | (NC << 8)); else __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NC; ++i) {
@@ -561,6 +585,7 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
         }
         // ---- moment triangle, L-outer, fully unrolled: sums[] and the tables are static registers ----
         // all n clip distances into registers in one burst (one wait), then the triangle touches no memory
+        STAMP(2)
         float d[NT], sums[NT];
 #pragma unroll
         for (int c = 0; c < NT; ++c) d[c] = (EXACT || c < n) ? ds[c * 64 + lane] : __builtin_inff();
@@ -608,6 +633,7 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
             else asm volatile("" : "+v"(ties), "+v"(lvl));
             __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP(3)
         if (TOPK && lvl != 0) {
             // some moment may enter the top-k: re-walk the flagged levels from the LDS distance column -- the same
             // left-to-right sums -- with the exact score, key and append
@@ -631,6 +657,7 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
             }
         }
         const bool tie = ties != 0;
+        STAMP(4)
         if (NR == 0 || __ballot(tie) == 0) continue;
 
         // ---- some lane has score == a rank key: re-walk this video exactly and break the ties by moment id ----
@@ -649,13 +676,19 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
         }
     }
 
+#ifdef VFR_SCORE_STAMPS
+    if (lane == 0 && a.stamps)
+        for (int i = 0; i < 6; ++i) atomicAdd(a.stamps + i, st_acc[i]);
+#endif
     if (active)
         for (int r = 0; r < NR; ++r)
             if (nlt[r]) atomicAdd(reinterpret_cast<unsigned long long *>(a.count_lt + r * a.Nq + qi), (unsigned long long)nlt[r]);
     if (TOPK) {
-        __threadfence_block();
-        lane_tighten(col, lane, a.k, &cnt, &thr);            // cut over-full columns close to k (merge sorts exactly)
-        __threadfence_block();
+        if (!a.keep_all) {
+            __threadfence_block();
+            lane_tighten(col, lane, a.k, &cnt, &thr);        // cut over-full columns close to k (merge sorts exactly)
+            __threadfence_block();
+        }
         a.buf_cnt[(size_t)task * 64 + lane] = active ? cnt : 0;
     }
 }
@@ -749,7 +782,8 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
         if (e < k) {
             const bool ok = key[i] != KEY_MAX;
             if (out_keys) out_keys[q * k + e] = key[i];
-            if (thr_seed && e == k - 1) thr_seed[q] = key[i];          // k-th best of the sample (KEY_MAX if fewer)
+            // k-th best so far (KEY_MAX if fewer): only ever tightens the stored threshold (it may hold a caller's seed)
+            if (thr_seed && e == k - 1 && key[i] < thr_seed[q]) thr_seed[q] = key[i];
             if (out_dist) {
                 out_dist[q * k + e] = ok ? __uint_as_float((unsigned)(key[i] >> 32)) : __builtin_inff();
                 out_idx[q * k + e] = ok ? (int64_t)(key[i] & 0xffffffffull) : -1;
@@ -853,10 +887,18 @@ static void plan_tasks(int64_t Nq, int Nv, int *groups, int *chunks)
 }
 static int kpl_for(int k) { return k <= 128 ? 4 : 8; }
 
-constexpr int PRE_VIDEOS = 256;     // sample scored exactly first; its k-th best key seeds every query's threshold
-constexpr int PRE_CHUNKS = 26;      // ~10 sample videos per wave-task
+// Threshold ladder of the top-k pass (k > 0, fast path, corpus large enough).  The fused kernel appends every moment that
+// beats the query's current threshold, so the threshold's quality decides how often its exact path runs:
+//   stage A  the first PRE_VIDEOS videos, one per wave-task, scored exactly by the cooperative-sort kernel -> their k-th key
+//   stage B  the next pre_b_videos() videos with the fused kernel under A's threshold -> merged with A: the k-th key of
+//            ~Nv/8 videos, which admits ~8k candidates per query in ...
+//   stage C  ... the rest of the corpus (the main launch); the final merge takes B's merged list as its `extra` input.
+// Every stage scores its own videos once; only the merges (0.3 ms) are added work.
+constexpr int PRE_VIDEOS = 32;
+constexpr int PRE_CHUNKS = 32;
+static int pre_b_videos(int Nv) { const int b = Nv / 8; return b > 1024 ? 1024 : b; }
 
-struct TopkWs { unsigned long long *buf, *buf_pre, *pre_keys; int *cnt, *cnt_pre; unsigned long long *thr; size_t total; };
+struct TopkWs { unsigned long long *buf, *buf_pre, *pre_keys, *pre_keys2; int *cnt, *cnt_pre; unsigned long long *thr; size_t total; };
 static TopkWs carve_topk(void *base, int64_t Nq, int Nv, int k)
 {
     TopkWs w{};
@@ -868,6 +910,7 @@ static TopkWs carve_topk(void *base, int64_t Nq, int Nv, int k)
     w.cnt = reinterpret_cast<int *>(take(tasks * 64 * 4));
     w.cnt_pre = reinterpret_cast<int *>(take(tasks_pre * 64 * 4));
     w.pre_keys = reinterpret_cast<unsigned long long *>(take(k > 0 ? (size_t)Nq * k * 8 : 0));
+    w.pre_keys2 = reinterpret_cast<unsigned long long *>(take(k > 0 ? (size_t)Nq * k * 8 : 0));
     w.buf_pre = reinterpret_cast<unsigned long long *>(take(k > 0 ? tasks_pre * 64 * cap * 8 : 0));
     w.buf = reinterpret_cast<unsigned long long *>(take(k > 0 ? tasks * 64 * cap * 8 : 0));
     w.total = off;
@@ -886,7 +929,8 @@ static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st, int *cap_tr
 {
     if (cap_transposed) *cap_transposed = 0;
     const int tasks = a.num_groups * a.num_chunks;
-    ProfScope prof(MODE == 0 ? SITE_SCORE_DENSE : (a.force_generic && a.k > 0) ? SITE_SCORE_PREPASS : a.k == 0 ? SITE_SCORE_RANK : SITE_SCORE_FUSED, st);
+    ProfScope prof(a.prof_site ? a.prof_site : MODE == 0 ? SITE_SCORE_DENSE : (a.force_generic && a.k > 0) ? SITE_SCORE_PREPASS
+                   : a.k == 0 ? SITE_SCORE_RANK : SITE_SCORE_FUSED, st);
     const int NTsel = a.ds_rows <= 6 ? 6 : 21, Msel = NTsel * (NTsel + 1) / 2;
     if (MODE == 1 && fast_applicable(a) && !a.force_generic) {
         const int NT = NTsel;
@@ -897,9 +941,26 @@ static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st, int *cap_tr
         const int NCg = 3, rows = (NT + NCg - 1) / NCg * NCg;
         const size_t lds = ((size_t)2 * NCg * FAST_D + (size_t)rows * 64 + (lox_lds ? (size_t)a.num_rank * NT * 64 : 0)) * sizeof(float);
         dim3 grid((unsigned)tasks);
+#ifdef VFR_SCORE_STAMPS
+        static unsigned long long *stamps_dev = nullptr;
+        if (!stamps_dev) (void)hipMalloc(&stamps_dev, 6 * 8);
+        (void)hipMemsetAsync(stamps_dev, 0, 6 * 8, st);
+        const_cast<ScoreArgs &>(a).stamps = stamps_dev;
+#endif
         if (NT == 6) { if (exact) launch_fast_nt<6, true>(a, kpl, grid, lds, st); else launch_fast_nt<6, false>(a, kpl, grid, lds, st); }
         else         { if (exact) launch_fast_nt<21, true>(a, kpl, grid, lds, st); else launch_fast_nt<21, false>(a, kpl, grid, lds, st); }
         VFR_CHECK_LAUNCH("score_fast_kernel");
+#ifdef VFR_SCORE_STAMPS
+        {
+            unsigned long long h[6];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h, stamps_dev, sizeof h, hipMemcpyDeviceToHost);
+            double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)h[i];
+            fprintf(stderr, "[stamps] k=%d nr=%d videos=%d tasks=%d  head %.1f%%  tighten/thr %.1f%%  distances %.1f%%  sqrt->regs+triangle %.1f%%  slow-levels %.1f%%  ties/loop %.1f%%  (%.3g ticks/wave)\n",
+                    a.k, a.num_rank, a.v_hi - a.v_lo, tasks, 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot,
+                    100 * h[4] / tot, 100 * h[5] / tot, tot / tasks);
+        }
+#endif
         return VFR_OK;
     }
     const size_t lds = (size_t)4 * a.ds_rows * 64 * sizeof(float);
@@ -1008,39 +1069,45 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
                                           : hipMemsetAsync(w.thr, 0xFF, (size_t)Nq * 8, st);
             if (e != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: threshold initialisation failed");
         }
-        // sample pre-pass (fast path only, corpus large enough): exact top-k of the first PRE_VIDEOS videos; its k-th
-        // key seeds thr_global, so the main pass appends ~k*Nv/PRE_VIDEOS candidates per query and never has to
-        // tighten.  The rank counters always run over the whole range in the main launch.
-        const bool prepass = k > 0 && !thr_seed && vfr::fast_applicable(a) && Nv >= 4 * vfr::PRE_VIDEOS;
+        // threshold ladder (see PRE_VIDEOS): stage A needs no seed; a caller-provided seed (the multi-GPU sample) replaces it
+        const bool ladder = k > 0 && vfr::fast_applicable(a) && Nv >= 1024;
+        const bool stage_a = ladder && !thr_seed;
         // small banks (a per-rank threshold sample, smoke-sized corpora): warm-up dominates, so use the
         // cooperative-compaction kernel with ~10 videos per task instead of many one-video tasks whose unsorted
         // output the merge kernel would have to sort
-        if (k > 0 && !thr_seed && Nv <= 2 * vfr::PRE_VIDEOS) {
+        if (k > 0 && !thr_seed && Nv <= 512) {
             a.force_generic = 1;
             const int c = Nv / 10 < 1 ? 1 : Nv / 10;
             a.num_chunks = c < a.num_chunks ? c : a.num_chunks;
         }
-        if (prepass) {
+        if (stage_a) {
+            // one video per wave-task, threshold +inf: every moment of the sample goes to the merge, which selects the k
+            // best (rank keys, when present, are counted in the same launch)
             vfr::ScoreArgs pre = a;
-            pre.v_lo = 0; pre.v_hi = vfr::PRE_VIDEOS; pre.num_chunks = vfr::PRE_CHUNKS; pre.num_rank = 0;
-            pre.rank_dist = nullptr; pre.rank_idx = nullptr; pre.buf = w.buf_pre; pre.buf_cnt = w.cnt_pre;
-            pre.force_generic = 1;      // warm-up heavy, tiny: the cooperative-sort kernel handles it best
+            pre.v_lo = 0; pre.v_hi = vfr::PRE_VIDEOS; pre.num_chunks = vfr::PRE_CHUNKS;
+            pre.buf = w.buf_pre; pre.buf_cnt = w.cnt_pre; pre.keep_all = 1; pre.prof_site = vfr::SITE_SCORE_PREPASS;
             if (int rc = vfr::launch_score<1>(pre, kpl, st, &cap_pre)) return rc;
             {
                 vfr::ProfScope prof(vfr::SITE_TOPK_MERGE, st);
                 merge(w.buf_pre, w.cnt_pre, vfr::PRE_CHUNKS, cap_pre, nullptr, w.pre_keys, w.thr, nullptr, nullptr);
             }
-            VFR_CHECK_LAUNCH("topk_merge_tasks_kernel(pre)");
+            VFR_CHECK_LAUNCH("topk_merge_tasks_kernel(A)");
             extra = w.pre_keys;
-            if (num_rank > 0) {                         // the rank counters must see the sample videos too
-                vfr::ScoreArgs rk = a;
-                rk.k = 0;
-                const bool fused_main = !(vfr::opt_score_split() && a.ds_rows > 6);
-                if (fused_main) rk.v_hi = vfr::PRE_VIDEOS;     // ranks of the sample here, the rest fused with top-k
-                if (int rc = vfr::launch_score<1>(rk, kpl, st)) return rc;
-                if (!fused_main) { a.num_rank = 0; a.rank_dist = nullptr; a.rank_idx = nullptr; }
-            }
             a.v_lo = vfr::PRE_VIDEOS;
+        }
+        if (ladder) {
+            const int nb = vfr::pre_b_videos(Nv);
+            vfr::ScoreArgs b = a;                       // same buffers as the main launch: the stream orders B, its merge, C
+            b.v_hi = a.v_lo + nb;
+            b.prof_site = vfr::SITE_SCORE_PREPASS;
+            if (int rc = vfr::launch_score<1>(b, kpl, st, &cap_t)) return rc;
+            {
+                vfr::ProfScope prof(vfr::SITE_TOPK_MERGE, st);
+                merge(w.buf, w.cnt, b.num_chunks, cap_t, extra, w.pre_keys2, w.thr, nullptr, nullptr);
+            }
+            VFR_CHECK_LAUNCH("topk_merge_tasks_kernel(B)");
+            extra = w.pre_keys2;
+            a.v_lo = b.v_hi;
         }
         if (int rc = vfr::launch_score<1>(a, kpl, st, &cap_t)) return rc;
     } else if (k > 0) {
