@@ -74,8 +74,10 @@ int vfr_linear_f32(const float *A, int64_t M, int K, const float *W, const float
  * Embedding gather [-> unit-norm x learnable length when len_tab != NULL, :62-64] -> BiLSTM(H),
  * h0 = c0 = 0, all T steps including pads -> h_n [fwd|bwd] -> Linear(2H, D).
  * tokens [B,T] int64; emb [vocab,E]; W_ih [4H,E], W_hh [4H,H], b_* [4H] (gate order i,f,g,o)
- * for the forward (_f) and reverse (_b) directions; Wfc [D,2H]; out [B,D].                      */
-size_t vfr_bilstm_workspace_bytes(int64_t B, int T, int E, int H);
+ * for the forward (_f) and reverse (_b) directions; Wfc [D,2H]; out [B,D].
+ * The workspace also holds the per-vocabulary input-projection table (emb x W_ih^T, both directions) that the
+ * recurrent steps start their gate chains from when vocab <= 32768 -- hence `vocab` in its size.  */
+size_t vfr_bilstm_workspace_bytes(int64_t B, int T, int E, int H, int vocab);
 int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *emb, int vocab, const float *len_tab,
                          const float *Wih_f, const float *Whh_f, const float *bih_f, const float *bhh_f,
                          const float *Wih_b, const float *Whh_b, const float *bih_b, const float *bhh_b, int E,

@@ -32,7 +32,7 @@ def test_version_and_error_plumbing_without_gpu():
     assert b"unknown option" in l.vfr_last_error()
     assert l.vfr_linear_f32(None, 1, 1, None, None, 1, 0, None, None) == -1
     assert l.vfr_score_topk_workspace_bytes(5000, 10000, 100) > 0
-    assert l.vfr_bilstm_workspace_bytes(64, 20, 100, 1000) > 0
+    assert l.vfr_bilstm_workspace_bytes(64, 20, 100, 1000, 400) > 0
 
 
 def test_hip_wrappers_refuse_cpu_tensors():

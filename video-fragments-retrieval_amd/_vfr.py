@@ -35,7 +35,7 @@ SIGNATURES = {
     "vfr_visual_mlp_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "vfr_visual_mlp_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vfr_linear_f32": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
-    "vfr_bilstm_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "vfr_bilstm_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "vfr_bilstm_final_f32": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp] + [_vp] * 8 + [_i32, _i32, _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
     "vfr_score_moments_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _vp, _vp]),
     "vfr_score_own_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp]),
@@ -198,7 +198,7 @@ def bilstm_final(tokens, emb, lstm: dict, Wfc, bfc, len_tab=None) -> torch.Tenso
     B, T = tokens.shape
     E, H, D = emb.shape[1], ws_[1].shape[1], Wfc.shape[0]
     out = torch.empty((B, D), dtype=torch.float32, device=tokens.device)
-    nbytes = lib().vfr_bilstm_workspace_bytes(B, T, E, H)
+    nbytes = lib().vfr_bilstm_workspace_bytes(B, T, E, H, emb.shape[0])
     ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=tokens.device)
     _check(lib().vfr_bilstm_final_f32(tokens.data_ptr(), B, T, emb.data_ptr(), emb.shape[0], _ptr(lt),
                                       *[w.data_ptr() for w in ws_], E, H, Wfc.data_ptr(), bfc.data_ptr(), D,

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t *__restrict__ 
 {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
-    int64_t tok = tokens[r];
+    int64_t tok = tokens ? tokens[r] : r;                    // null: row r is vocabulary entry r
     tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);   // never read outside the table
     const float *e = emb + tok * E;
     float *x = X + r * E;
@@ -120,6 +120,18 @@ __global__ void active_rows_kernel(const int *__restrict__ len, int64_t B, int T
 }
 
 // [B+1 sorted rows, 2H] -> [B, 2H] in query order; an all-pad query's reverse half is the pad row's
+// table row of GEMM row m at time t: the (clamped) token of query xrow[m]  ->  tokidx [T][R]
+__global__ __launch_bounds__(256) void token_index_kernel(const int64_t *__restrict__ tok_ext, const int *__restrict__ xrow,
+                                                          int64_t R, int T, int vocab, int *__restrict__ tokidx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * T) return;
+    const int t = (int)(i / R);
+    const int64_t m = i - (int64_t)t * R;
+    int64_t tok = tok_ext[(int64_t)xrow[m] * T + t];
+    tokidx[i] = (int)(tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok));
+}
+
 __global__ __launch_bounds__(256) void unsort_rows_kernel(const float *__restrict__ hs, const int *__restrict__ row_of,
                                                           const int *__restrict__ len, int64_t B, int H,
                                                           float *__restrict__ out)
@@ -132,13 +144,19 @@ __global__ __launch_bounds__(256) void unsort_rows_kernel(const float *__restric
     out[i] = hs[src * 2 * H + j];
 }
 
+// Vocabularies up to this many entries get the input-projection table (P = emb x W_ih^T per entry, 2 directions):
+// 2 x 32768 x 4096 floats = 1 GB at H = 1000 -- nothing on a 288 GB part, and far fewer rows than B*T once B is large.
+constexpr int VOCAB_TABLE_MAX = 32768;
+static bool use_vocab_table(int64_t B, int T, int vocab) { return vocab <= VOCAB_TABLE_MAX && (int64_t)vocab <= 4 * B * T; }
+
 struct LstmWs {
-    float *X, *gates, *c, *c2, *hcat, *hcat2, *hfinal;
+    float *X, *gates, *c, *c2, *hcat, *hcat2, *hfinal, *xv, *wperm, *ptab;
+    int *tokidx;
     int64_t *tok_ext;
     int *len, *row_of, *xrow, *mcount, *hist;
     size_t total;
 };
-static LstmWs carve(void *base, int64_t B, int T, int E, int H)
+static LstmWs carve(void *base, int64_t B, int T, int E, int H, int vocab)
 {
     LstmWs w{};
     size_t off = 0;
@@ -158,6 +176,13 @@ static LstmWs carve(void *base, int64_t B, int T, int E, int H)
     w.xrow = reinterpret_cast<int *>(take_b(R * sizeof(int)));
     w.mcount = reinterpret_cast<int *>(take_b((size_t)(T + 1) * sizeof(int)));
     w.hist = reinterpret_cast<int *>(take_b((size_t)cdiv(R, SORT_BLOCK) * (T + 1) * sizeof(int)));
+    if (use_vocab_table(B, T, vocab)) {
+        const size_t np = (size_t)cdiv(H, 32) * 128;
+        w.xv = take((size_t)vocab * E);
+        w.wperm = take(2 * np * E);
+        w.ptab = take(2 * (size_t)vocab * np);
+        w.tokidx = reinterpret_cast<int *>(take_b(R * T * sizeof(int)));
+    }
     w.total = off;
     return w;
 }
@@ -166,10 +191,10 @@ static LstmWs carve(void *base, int64_t B, int T, int E, int H)
 
 extern "C" {
 
-size_t vfr_bilstm_workspace_bytes(int64_t B, int T, int E, int H)
+size_t vfr_bilstm_workspace_bytes(int64_t B, int T, int E, int H, int vocab)
 {
     if (B < 0 || T < 0 || E < 0 || H < 0) return 0;
-    return vfr::carve(nullptr, B, T, E, H).total;
+    return vfr::carve(nullptr, B, T, E, H, vocab).total;
 }
 
 int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *emb, int vocab, const float *len_tab,
@@ -182,11 +207,11 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
                     out && B >= 0 && T > 0 && E > 0 && H > 0 && D > 0 && vocab > 0,
                 VFR_EINVAL, "vfr_bilstm_final_f32: bad argument");
     if (B == 0) return VFR_OK;
-    VFR_REQUIRE(workspace && workspace_bytes >= vfr_bilstm_workspace_bytes(B, T, E, H), VFR_EWORKSPACE,
+    VFR_REQUIRE(workspace && workspace_bytes >= vfr_bilstm_workspace_bytes(B, T, E, H, vocab), VFR_EWORKSPACE,
                 "vfr_bilstm_final_f32: workspace %zu < %zu bytes", workspace_bytes,
-                vfr_bilstm_workspace_bytes(B, T, E, H));
+                vfr_bilstm_workspace_bytes(B, T, E, H, vocab));
     hipStream_t st = vfr::as_stream(stream);
-    vfr::LstmWs w = vfr::carve(workspace, B, T, E, H);
+    vfr::LstmWs w = vfr::carve(workspace, B, T, E, H, vocab);
     const float *Wih[2] = {Wih_f, Wih_b}, *Whh[2] = {Whh_f, Whh_b};
     const float *bih[2] = {bih_f, bih_b}, *bhh[2] = {bhh_f, bhh_b};
     const int G = 4 * H;
@@ -199,10 +224,17 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
         hipMemsetAsync(w.c, 0, (size_t)2 * R * H * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(w.hcat, 0, (size_t)R * 2 * H * sizeof(float), st) != hipSuccess)
         return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: buffer initialisation failed");
+    const bool fused = vfr::opt_gemm() != 0 && (E % 4) == 0 && (H % 4) == 0 &&
+                       ((((uintptr_t)Wih_f) | ((uintptr_t)Whh_f) | ((uintptr_t)Wih_b) | ((uintptr_t)Whh_b)) & 15) == 0;
+    const bool table = fused && vfr::use_vocab_table(B, T, vocab);
     {
     vfr::ProfScope prof(vfr::SITE_EMBED, st);
-    hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(R * T, 256)), dim3(256), 0, st, w.tok_ext, R * T, vocab,
-                       emb, len_tab, E, w.X);
+    if (table)          // one embedded row per VOCABULARY entry (the steps start their chains from the projection table)
+        hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(vocab, 256)), dim3(256), 0, st, (const int64_t *)nullptr,
+                           (int64_t)vocab, vocab, emb, len_tab, E, w.xv);
+    else
+        hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(R * T, 256)), dim3(256), 0, st, w.tok_ext, R * T, vocab,
+                           emb, len_tab, E, w.X);
     hipLaunchKernelGGL(vfr::query_length_kernel, dim3((unsigned)vfr::cdiv(B, 256)), dim3(256), 0, st, tokens, B, T, w.len);
     hipLaunchKernelGGL(vfr::length_hist_kernel, dim3((unsigned)vfr::cdiv(B, vfr::SORT_BLOCK)), dim3(vfr::SORT_BLOCK), 0, st,
                        w.len, B, T, w.hist);
@@ -212,8 +244,22 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
     }
     VFR_CHECK_LAUNCH("bilstm row bookkeeping");
     float *h_sorted = w.hcat;
-    const bool fused = vfr::opt_gemm() != 0 && (E % 4) == 0 && (H % 4) == 0 &&
-                       ((((uintptr_t)Wih_f) | ((uintptr_t)Whh_f) | ((uintptr_t)Wih_b) | ((uintptr_t)Whh_b)) & 15) == 0;
+    const int64_t NP = vfr::cdiv(H, 32) * 128;              // tile-column count of the fused step (4 gates x 32 units per tile)
+    if (table) {
+        // P_d [vocab, NP] = emb_rows x W_ih,d^T (rows of W_ih permuted into the step's tile-column order): the first E
+        // terms of every gate chain, once per vocabulary entry instead of once per (query, time)
+        vfr::GemmArgs gp[2]{};
+        for (int d = 0; d < 2; ++d) {
+            if (int rc = vfr::lstm_permute_rows(Wih[d], H, E, w.wperm + (size_t)d * NP * E, st)) return rc;
+            gp[d].A = w.xv; gp[d].lda = E; gp[d].W = w.wperm + (size_t)d * NP * E; gp[d].ldw = E;
+            gp[d].out = w.ptab + (size_t)d * vocab * NP; gp[d].ldo = NP; gp[d].M = vocab; gp[d].N = (int)NP; gp[d].K = E;
+            gp[d].site = vfr::SITE_GEMM_LSTM_IN;
+        }
+        if (int rc = vfr::gemm_nt_pair(gp[0], gp[1], st)) return rc;
+        hipLaunchKernelGGL(vfr::token_index_kernel, dim3((unsigned)vfr::cdiv(R * T, 256)), dim3(256), 0, st, w.tok_ext, w.xrow, R, T,
+                           vocab, w.tokidx);
+        VFR_CHECK_LAUNCH("token_index_kernel");
+    }
     if (fused) {
         // one MFMA launch per time step for both directions: K = [x_t (E) | h (H)], gate epilogue fused; the reverse
         // direction only touches the rows that have reached a real token (lstm_mcount), the rest ride on row 0
@@ -229,6 +275,11 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
                 g[d].lstm_h = hout + (size_t)d * H; g[d].lstm_ldh = 2 * H;
                 g[d].lstm_H = H; g[d].out = hout; g[d].site = vfr::SITE_GEMM_LSTM_REC;
                 g[d].lstm_xrow = w.xrow; g[d].lstm_mcount = d ? w.mcount : nullptr; g[d].lstm_step = step;
+                if (table) {
+                    g[d].A = g[d].A2; g[d].W = g[d].W2; g[d].lda = g[d].lda2; g[d].ldw = g[d].ldw2; g[d].K = 0;   // no x segment
+                    g[d].Cin = w.ptab + (size_t)d * vocab * NP; g[d].ldc = NP;
+                    g[d].lstm_tok = w.tokidx + (size_t)t * R;
+                }
             }
             if (int rc = vfr::lstm_step_pair(g[0], g[1], st)) return rc;
             // reverse-direction rows that have not joined yet keep (unused) stale values in the ping-pong buffers; they

@@ -113,6 +113,12 @@ __device__ __forceinline__ float4 load4_guard(const float *__restrict__ P, int64
 }
 
 struct GemmPair { GemmArgs p[2]; };
+#ifdef VFR_GEMM_STAMPS
+__device__ unsigned long long g_gemm_stamps[4];
+#define GSTAMP(i) { if (LSTM) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); gst[i] += t_ - gt0; gt0 = t_; } }
+#else
+#define GSTAMP(i)
+#endif
 
 template <bool VEC, bool CONV, bool LSTM = false>
 __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
@@ -128,7 +134,30 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     const int64_t Mprev = (LSTM && g.lstm_mcount) ? (g.lstm_step > 0 ? (int64_t)g.lstm_mcount[g.lstm_step - 1] : 1) : Mrows;
     if (LSTM && m0 >= Mrows) return;
 
+#ifdef VFR_GEMM_STAMPS
+    unsigned long long gst[4] = {0, 0, 0, 0}, gt0 = __builtin_amdgcn_s_memtime();
+#endif
     f32x16 acc[2][2];
+    if (LSTM && g.lstm_tok) {
+        // chains start from the vocabulary input-projection table: P[lstm_tok[row]][tile column].  Two batched load
+        // rounds (all 32 table-row indices, then all 64 accumulators), not 32 dependent pairs one after the other.
+        int64_t prow[2][16];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                prow[mi][r] = (int64_t)g.lstm_tok[row < Mrows ? row : Mrows - 1];
+            }
+        const float *pcol = g.Cin + (int64_t)blockIdx.y * MBN + wn * 64 + l31;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[mi][0][r] = pcol[prow[mi][r] * g.ldc];
+                acc[mi][1][r] = pcol[prow[mi][r] * g.ldc + 32];
+            }
+    } else {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -139,6 +168,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 const int col = n0 + wn * 64 + ni * 32 + l31;
                 acc[mi][ni][r] = (g.Cin && row < g.M && col < g.N) ? g.Cin[row * g.ldc + col] : 0.0f;
             }
+    }
 
     float4 ra[4], rw[4];
     // Staging loads.  Full K-tiles use UNCONDITIONAL loads (row index clamped into range; rows past M / N are
@@ -292,6 +322,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     auto gload_main = [&](int k0) { if (LSTM) gload_seg(k0); else if (CONV) gload_conv(k0); else gload_full(k0); };
     if (nk_full > 0) { gload_main(0); swrite(0); }
     __syncthreads();
+    GSTAMP(0)
     for (int kt = 0; kt < nk_full; ++kt) {
         const int nxt = kt + 1 < nk_full ? kt + 1 : nk_full - 1;
         gload_main(nxt * MBK);
@@ -313,6 +344,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         compute(nk_full % VFR_GEMM_NBUF);
     }
 
+    GSTAMP(1)
     if (LSTM) {
         // lane l31 < 16 holds gates (i | g) of unit u in tiles ni = 0 | 1, lane l31 + 16 holds (f | o) of the same unit.
         // The pair swaps what the other needs and splits the rows: the low lane finishes even r, the high lane odd r.
@@ -321,26 +353,47 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         const int uc = valid ? unit : H - 1;
         const float bi = g.bias[uc] + g.bias2[uc], bf = g.bias[H + uc] + g.bias2[H + uc];
         const float bg = g.bias[2 * H + uc] + g.bias2[2 * H + uc], bo = g.bias[3 * H + uc] + g.bias2[3 * H + uc];
+        // item (mi, j): row r = 2j + hi_lane.  Everything is branch-free and batched: 16 previous-cell loads up front (clamped
+        // addresses), 32 exchanges (each lane sends only the half its partner finishes), 16 independent gate evaluations the
+        // scheduler can interleave, predicated stores last.
+        float cprev[2][8], xi[2][8], xf[2][8], xg[2][8], xo[2][8];
+        int64_t orow[2][8];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p0 = __shfl_xor(acc[mi][0][r], 16, 64);      // partner's tile-0 gate (f for low, i for high)
-                const float p1 = __shfl_xor(acc[mi][1][r], 16, 64);      // partner's tile-1 gate (o for low, g for high)
-                const bool mine = ((r & 1) != 0) == hi_lane;
-                const int64_t row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (mine && valid && row < Mrows) {
-                    const float xi = hi_lane ? p0 : acc[mi][0][r], xf = hi_lane ? acc[mi][0][r] : p0;
-                    const float xg = hi_lane ? p1 : acc[mi][1][r], xo = hi_lane ? acc[mi][1][r] : p1;
-                    const float ig = c_sigmoidf(xi + bi);
-                    const float fg = c_sigmoidf(xf + bf);
-                    const float gg = c_tanhf(xg + bg);
-                    const float og = c_sigmoidf(xo + bo);
-                    const float cn = __builtin_fmaf(fg, g.lstm_cin[(row >= Mprev ? 0 : row) * H + unit], ig * gg);
-                    g.lstm_c[row * H + unit] = cn;
-                    g.lstm_h[row * g.lstm_ldh + unit] = og * c_tanhf(cn);
+            for (int j = 0; j < 8; ++j) {
+                const int r0 = 2 * j, r1 = 2 * j + 1;
+                const int64_t rowe = m0 + wm * 64 + mi * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * h;     // r1's row = rowe + 1
+                const int64_t row = rowe + (hi_lane ? 1 : 0);
+                orow[mi][j] = row;
+                const int64_t rc = row < Mrows ? row : Mrows - 1;
+                cprev[mi][j] = g.lstm_cin[(rc >= Mprev ? 0 : rc) * H + uc];
+                const float own0 = hi_lane ? acc[mi][0][r1] : acc[mi][0][r0], own1 = hi_lane ? acc[mi][1][r1] : acc[mi][1][r0];
+                const float snd0 = hi_lane ? acc[mi][0][r0] : acc[mi][0][r1], snd1 = hi_lane ? acc[mi][1][r0] : acc[mi][1][r1];
+                const float p0 = __shfl_xor(snd0, 16, 64), p1 = __shfl_xor(snd1, 16, 64);
+                xi[mi][j] = hi_lane ? p0 : own0; xf[mi][j] = hi_lane ? own0 : p0;
+                xg[mi][j] = hi_lane ? p1 : own1; xo[mi][j] = hi_lane ? own1 : p1;
+            }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float ig = c_sigmoidf(xi[mi][j] + bi);
+                const float fg = c_sigmoidf(xf[mi][j] + bf);
+                const float gg = c_tanhf(xg[mi][j] + bg);
+                const float og = c_sigmoidf(xo[mi][j] + bo);
+                const float cn = __builtin_fmaf(fg, cprev[mi][j], ig * gg);
+                const float hn = og * c_tanhf(cn);
+                if (valid && orow[mi][j] < Mrows) {
+                    g.lstm_c[orow[mi][j] * H + unit] = cn;
+                    g.lstm_h[orow[mi][j] * g.lstm_ldh + unit] = hn;
                 }
             }
+        GSTAMP(2)
+#ifdef VFR_GEMM_STAMPS
+        if (lane == 0) for (int i = 0; i < 3; ++i) atomicAdd(&g_gemm_stamps[i], gst[i]);
+        if (tid == 0) atomicAdd(&g_gemm_stamps[3], 1ull);
+#endif
         return;
     }
 #pragma unroll
@@ -383,6 +436,28 @@ __global__ __launch_bounds__(256) void repack_rows_kernel(const float *__restric
     dst[i] = src[r * ld_src + c];
 }
 
+// W [4H, E] -> the fused step's tile-column order [128 * ceil(H/32), E] (zero rows for units >= H): tile column
+// c = 128*tile + rr holds gate 2*((rr>>5)&1) + ((rr>>4)&1) of unit 32*tile + 16*(rr>>6) + (rr&15)
+__global__ __launch_bounds__(256) void lstm_permute_rows_kernel(const float *__restrict__ W, int H, int E, int ncols,
+                                                                float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)ncols * E) return;
+    const int c = (int)(i / E), k = (int)(i - (int64_t)c * E);
+    const int tile = c >> 7, rr = c & 127;
+    const int gate = ((rr >> 5) & 1) * 2 + ((rr >> 4) & 1), unit = tile * 32 + (rr >> 6) * 16 + (rr & 15);
+    out[i] = unit < H ? W[((int64_t)gate * H + unit) * E + k] : 0.0f;
+}
+
+int lstm_permute_rows(const float *W, int H, int E, float *out, hipStream_t st)
+{
+    const int ncols = (int)cdiv(H, 32) * MBN;
+    ProfScope prof(SITE_REPACK, st);
+    hipLaunchKernelGGL(lstm_permute_rows_kernel, dim3((unsigned)cdiv((int64_t)ncols * E, 256)), dim3(256), 0, st, W, H, E, ncols, out);
+    VFR_CHECK_LAUNCH("lstm_permute_rows_kernel");
+    return VFR_OK;
+}
+
 int repack_rows(const float *src, int64_t ld_src, int rows, int cols, float *dst, hipStream_t st)
 {
     if (rows <= 0 || cols <= 0) return VFR_OK;
@@ -404,6 +479,8 @@ int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
     for (const GemmArgs *g : {&g0, &g1}) {
         VFR_REQUIRE(g->A && g->W && g->A2 && g->W2 && g->bias && g->bias2 && g->lstm_c && g->lstm_cin && g->lstm_h && g->lstm_H > 0, VFR_EINVAL,
                     "lstm_step_pair: bad argument");
+        VFR_REQUIRE(!g->lstm_tok || (g->Cin && g->K == 0 && g->ldc >= cdiv(g->lstm_H, 32) * MBN), VFR_EINVAL,
+                    "lstm_step_pair: the input-projection table needs Cin [vocab, >= 128*ceil(H/32)] and K == 0");
         VFR_REQUIRE(((g->lda | g->ldw | g->lda2 | g->ldw2 | g->K | g->K2) & 3) == 0 &&
                         ((((uintptr_t)g->A) | ((uintptr_t)g->W) | ((uintptr_t)g->A2) | ((uintptr_t)g->W2)) & 15) == 0,
                     VFR_EUNSUPPORTED, "lstm_step_pair: E, H and the operand strides must be multiples of 4 floats, 16-byte aligned");
@@ -413,6 +490,16 @@ int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
     dim3 grid((unsigned)cdiv(g0.M, MBM), (unsigned)cdiv(g0.lstm_H, 32), 2);
     hipLaunchKernelGGL(lstm_step_mfma_pair, grid, dim3(256), 0, st, gp);
     VFR_CHECK_LAUNCH("lstm_step_mfma_pair");
+#ifdef VFR_GEMM_STAMPS
+    if (g0.lstm_step == 19 || g0.lstm_step == 0) {
+        unsigned long long h[4];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_stamps), sizeof h);
+        const double tot = (double)h[0] + h[1] + h[2];
+        fprintf(stderr, "[gemm stamps] step %d: tiles so far %llu  prologue %.1f%%  main loop %.1f%%  epilogue %.1f%%  (%.0f ticks per wave-tile)\n",
+                g0.lstm_step, h[3], 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, tot / (4.0 * h[3]));
+    }
+#endif
     return VFR_OK;
 }
 

@@ -85,6 +85,11 @@ struct GemmArgs {
     // lstm_mcount[s] = number of active rows at step s (rows are sorted so the active set is a prefix); rows that join
     // at step s (>= lstm_mcount[s-1], or >= 1 at s = 0) take their incoming state from row 0, the all-pad row.
     const int *lstm_xrow; const int *lstm_mcount; int lstm_step;
+    // input-projection table (lstm_tok != null, K == 0): the x-part of every gate chain depends only on the token, so it
+    // is computed once per VOCABULARY entry (Cin = P [vocab, ldc], columns in the permuted tile order) and GEMM row m's
+    // accumulators start from P[lstm_tok[m]] (the clamped token of row m's query at this step) -- the same chain,
+    // continued over h.
+    const int *lstm_tok;
 };
 int gemm_nt(const GemmArgs &g, hipStream_t st);
 // two GEMMs of identical shape as ONE grid (blockIdx.z picks the problem): fills the chip when one alone leaves a
@@ -92,6 +97,8 @@ int gemm_nt(const GemmArgs &g, hipStream_t st);
 int gemm_nt_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st);
 // fused LSTM step for both directions (see GemmArgs::lstm_H)
 int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st);
+// W_ih [4H, E] -> [128*ceil(H/32), E] in the fused step's tile-column order (for the vocabulary input-projection table)
+int lstm_permute_rows(const float *W, int H, int E, float *out, hipStream_t st);
 // copy a [rows, cols] block out of a wider row-major matrix into a dense, 16-byte aligned buffer
 int repack_rows(const float *src, int64_t ld_src, int rows, int cols, float *dst, hipStream_t st);
 
