@@ -113,6 +113,7 @@ __device__ __forceinline__ float4 load4_guard(const float *__restrict__ P, int64
 }
 
 struct GemmPair { GemmArgs p[2]; };
+
 #ifdef VFR_GEMM_STAMPS
 __device__ unsigned long long g_gemm_stamps[4];
 #define GSTAMP(i) { if (LSTM) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); gst[i] += t_ - gt0; gt0 = t_; } }
@@ -405,6 +406,20 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             float badd = 0.0f;
             if (g.epi & EPI_BIAS2) badd = g.bias[col] + g.bias2[col];
             else if (g.epi & EPI_BIAS) badd = g.bias[col];
+            if (g.epi & EPI_VIS) {
+                // hidden layer of the clip encoder fused here: the S array never exists in HBM
+                const float w0 = g.vis_w0[col], w1 = g.vis_w1[col], b = g.bias[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row >= g.M) continue;
+                    const float te0 = g.vis_te[2 * row], te1 = g.vis_te[2 * row + 1];
+                    const float te = __builtin_fmaf(te1, w1, __builtin_fmaf(te0, w0, 0.0f));
+                    const float x = ((acc[mi][ni][r] + g.vis_cx[(int64_t)g.vis_row[row] * g.N + col]) + te) + b;
+                    g.out[row * g.ldo + col] = x > 0.0f ? x : 0.0f;
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;

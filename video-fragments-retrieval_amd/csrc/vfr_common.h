@@ -60,6 +60,7 @@ enum : int {
     EPI_BIAS = 1,      // + bias[n] after the chain
     EPI_BIAS2 = 2,     // + (bias[n] + bias2[n])   (LSTM: b_ih + b_hh)
     EPI_RELU = 4,      // max(x, 0) last
+    EPI_VIS = 8,       // clip-encoder hidden layer: x = ((chain + vis_cx[vis_row[m]][n]) + fma(te1, vis_w1[n], fma(te0, vis_w0[n], 0))) + bias[n]
 };
 struct GemmArgs {
     const float *A; int64_t lda;
@@ -70,6 +71,9 @@ struct GemmArgs {
     int64_t M; int N; int K;
     int epi;
     int site;                          // profiler site (SITE_NONE = not instrumented)
+    // EPI_VIS (MFMA kernel only): vis_row[m] = video of clip row m, vis_te[m] = (t/n, (t+1)/n), vis_cx [videos, N] = the
+    // per-video context chains, vis_w0 / vis_w1 [N] = the two temporal-endpoint weight columns
+    const int *vis_row; const float *vis_te; const float *vis_cx; const float *vis_w0, *vis_w1;
     // implicit-GEMM 3x3 convolution (conv_cin > 0): A is an NHWC activation [B, conv_h, conv_w, conv_cin]; row m is the
     // output pixel (n, oy, ox), column k = (ky*3 + kx)*conv_cin + ci reads x[n][oy+ky-1][ox+kx-1][ci] (0 outside).
     // M = B*conv_h*conv_w, K = 9*conv_cin (conv_cin % 4 == 0), out [M, N] is the NHWC output.
