@@ -711,7 +711,14 @@ static void launch_fast_nt(const ScoreArgs &a, int kpl, dim3 grid, size_t lds, h
 #undef VFR_FAST
 }
 
-// one wave per query: merge the per-chunk sorted lists into the final top-k
+// one wave per query: merge the per-chunk candidate lists (+ an optional pre-sorted k-list) into the final top-k.
+//   * the chunk lists are consumed as ONE flat sequence: all counts are loaded and prefix-summed first, then CAP keys per
+//     round are gathered with all loads in flight at once (each element finds its (chunk, offset) by binary search in the
+//     LDS prefix table) -- not one dependent count + key round trip per chunk;
+//   * the pool of survivors lives in LDS; an incoming key is appended (ballot + mbcnt) only if it beats the running k-th
+//     key, so after the first two rounds almost nothing is appended and the 512-key bitonic sorts (ds_bpermute-bound,
+//     ~10 us each) drop from one per 412 keys to a handful per query.
+constexpr int MERGE_MAX_CHUNKS = 1024;                   // plan_tasks never makes more
 template <int KPL>
 __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned long long *__restrict__ buf,
                                                                const int *__restrict__ buf_cnt, int num_groups,
@@ -723,59 +730,72 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
                                                                int64_t *__restrict__ out_idx)
 {
     constexpr int CAP = KPL * 64;
-    const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wv;
     if (q >= Nq) return;
     const int group = (int)(q >> 6), ql = (int)(q & 63);
+    __shared__ int pre_s[4][MERGE_MAX_CHUNKS + 1];
+    __shared__ unsigned long long pool_s[4][CAP];
+    int *pre = pre_s[wv];
+    unsigned long long *pool = pool_s[wv];
     unsigned long long key[KPL];
+    unsigned long long thr = KEY_MAX;                    // running k-th best key (KEY_MAX until k keys have been sorted)
+    int fill = 0;                                        // pool[0, fill) holds the survivors
+
+    auto lds_sync = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); };
+    auto sort_pool = [&](bool final_pass) {              // pool -> registers -> sorted; keep the k best
+        lds_sync();
 #pragma unroll
-    for (int i = 0; i < KPL; ++i) key[i] = KEY_MAX;
-    int fill = 0;         // key elements [0, fill) hold candidates, the rest KEY_MAX
-    for (int ch = 0; ch < num_chunks; ++ch) {
-        const size_t slot = ((size_t)ch * num_groups + group) * 64 + ql;
-        const int c = buf_cnt[slot];
-        // cap_t > 0: the fast kernel's transposed columns [task][slot][lane]; else lane-major [task][lane][CAP]
-        const unsigned long long *src = cap_t > 0 ? buf + ((size_t)ch * num_groups + group) * 64 * cap_t + ql
-                                                  : buf + slot * CAP;
-        const size_t stride = cap_t > 0 ? 64 : 1;
-        int off = 0;
-        while (off < c) {
-            if (fill == CAP) {            // full: sort, keep the k best (k < CAP, so this frees room)
-                wave_sort<KPL>(key, lane);
+        for (int i = 0; i < KPL; ++i) { const int e = i * 64 + lane; key[i] = e < fill ? pool[e] : KEY_MAX; }
+        wave_sort<KPL>(key, lane);
+        if (final_pass) return;
+        lds_sync();
 #pragma unroll
-                for (int i = 0; i < KPL; ++i)
-                    if (i * 64 + lane >= k) key[i] = KEY_MAX;
-                fill = k;
-            }
-            const int room = CAP - fill, take = (c - off) < room ? (c - off) : room;
+        for (int i = 0; i < KPL; ++i) { const int e = i * 64 + lane; if (e < k) pool[e] = key[i]; }
+        if (fill >= k) thr = key_at<KPL>(key, k - 1);
+        fill = fill < k ? fill : k;
+    };
+    auto append = [&](unsigned long long x, bool have) {  // one candidate per lane
+        if (fill + 64 > CAP) sort_pool(false);
+        const bool pass = have && x < thr;
+        const unsigned long long m = __ballot(pass);
+        if (pass) pool[fill + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = x;
+        fill += __builtin_popcountll(m);
+    };
+
+    int total = 0;
+    for (int base = 0; base < num_chunks; base += 64) {
+        const int ch = base + lane;
+        const int c = ch < num_chunks ? buf_cnt[((size_t)ch * num_groups + group) * 64 + ql] : 0;
+        int incl = c;                                   // inclusive wave scan
 #pragma unroll
-            for (int i = 0; i < KPL; ++i) {
-                int e = i * 64 + lane;
-                if (e >= fill && e < fill + take) key[i] = src[(size_t)(off + e - fill) * stride];
-            }
-            fill += take; off += take;
-        }
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        if (ch < num_chunks) pre[ch + 1] = total + incl;
+        total += __shfl(incl, 63, 64);
     }
-    if (extra) {                          // a pre-sorted k-list per query (the sample pre-pass), KEY_MAX padded
-        int off = 0;
-        while (off < k) {
-            if (fill == CAP) {
-                wave_sort<KPL>(key, lane);
+    if (lane == 0) pre[0] = 0;
+    lds_sync();
+    for (int done = 0; done < total; done += CAP) {
+        unsigned long long x[KPL];
 #pragma unroll
-                for (int i = 0; i < KPL; ++i)
-                    if (i * 64 + lane >= k) key[i] = KEY_MAX;
-                fill = k;
+        for (int i = 0; i < KPL; ++i) {
+            const int gi = done + i * 64 + lane;
+            x[i] = KEY_MAX;
+            if (gi < total) {
+                int lo = 0, hi = num_chunks;            // largest ch with pre[ch] <= gi  (pre[num_chunks] = total > gi)
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pre[mid] <= gi) lo = mid; else hi = mid; }
+                const int off = gi - pre[lo];
+                // cap_t > 0: the fast kernel's transposed columns [task][slot][lane]; else lane-major [task][lane][CAP]
+                x[i] = cap_t > 0 ? buf[(((size_t)lo * num_groups + group) * cap_t + off) * 64 + ql]
+                                 : buf[(((size_t)lo * num_groups + group) * 64 + ql) * CAP + off];
             }
-            const int room = CAP - fill, take = (k - off) < room ? (k - off) : room;
-#pragma unroll
-            for (int i = 0; i < KPL; ++i) {
-                int e = i * 64 + lane;
-                if (e >= fill && e < fill + take) key[i] = extra[q * k + off + e - fill];
-            }
-            fill += take; off += take;
         }
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) append(x[i], done + i * 64 + lane < total);
     }
-    wave_sort<KPL>(key, lane);
+    if (extra)                            // a pre-sorted k-list per query (the threshold ladder's previous stage), KEY_MAX padded
+        for (int off = 0; off < k; off += 64) append(off + lane < k ? extra[q * k + off + lane] : KEY_MAX, off + lane < k);
+    sort_pool(true);
 #pragma unroll
     for (int i = 0; i < KPL; ++i) {
         int e = i * 64 + lane;
