@@ -56,7 +56,8 @@ def site_work(site, cfg):
     """Algorithmic FLOP per launch of an instrumented site (SURVEY.md 8d figures), and which roof bounds it."""
     B, C, Nv, H, E, F, hid, D, n, Nq = (cfg[k] for k in ("Bq", "C", "Nv", "H", "E", "F", "hid", "D", "n", "Nq"))
     M = n * (n + 1) // 2
-    pre = (32 + min(1024, Nv // 8)) if Nv >= 1024 else 0     # threshold ladder of the top-k pass (score.hip: PRE_VIDEOS, pre_b_videos)
+    na = min(32, Nv)                                          # threshold ladder of the top-k pass (score.hip: PRE_VIDEOS, pre_b_videos)
+    pre = na + (min(1024, (Nv - na) // 8) if Nv - na >= 256 else 0)
     table = {
         # fused step [x_t | h] x [Wih | Whh]^T; rows actually processed per launch, averaged over the T steps: the
         # forward direction steps every query (+1 all-pad row), the reverse direction only the queries that have
@@ -72,7 +73,7 @@ def site_work(site, cfg):
         # first fused launch whose merged k-th key is the threshold of the main fused launch over the rest.
         "score_fused": float(Nq) * max(Nv - pre, 0) * (2 * n * D + n + 2 * M),
         "score_rank": float(Nq) * min(Nv, 32) * (2 * n * D + n + 2 * M),
-        "score_prepass": float(Nq) * pre / 2 * (2 * n * D + n + 2 * M),       # two launches: stage A + stage B, averaged
+        "score_prepass": float(Nq) * pre / (2 if pre > na else 1) * (2 * n * D + n + 2 * M),   # stage A (+ stage B), averaged per launch
     }
     return table.get(site)
 

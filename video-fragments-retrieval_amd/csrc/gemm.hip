@@ -336,7 +336,9 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         // refill it now (overlapping the other waves' MFMAs); one barrier per K-tile
         if (VFR_GEMM_NBUF == 1) __syncthreads();     // single buffer: everyone must finish reading before the refill
         swrite((kt + 1) % VFR_GEMM_NBUF);
+#ifndef VFR_GEMM_NOSYNC
         __syncthreads();
+#endif
     }
     if (!CONV && !LSTM && (g.K % MBK)) {   // partial last tile: guarded loads, zero padded (fma(0,0,acc) == acc)
         gload_tail(nk_full * MBK);

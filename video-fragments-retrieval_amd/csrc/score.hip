@@ -1089,34 +1089,34 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
                                           : hipMemsetAsync(w.thr, 0xFF, (size_t)Nq * 8, st);
             if (e != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: threshold initialisation failed");
         }
-        // threshold ladder (see PRE_VIDEOS): stage A needs no seed; a caller-provided seed (the multi-GPU sample) replaces it
-        const bool ladder = k > 0 && vfr::fast_applicable(a) && Nv >= 1024;
-        const bool stage_a = ladder && !thr_seed;
-        // small banks (a per-rank threshold sample, smoke-sized corpora): warm-up dominates, so use the
-        // cooperative-compaction kernel with ~10 videos per task instead of many one-video tasks whose unsorted
-        // output the merge kernel would have to sort
-        if (k > 0 && !thr_seed && Nv <= 512) {
-            a.force_generic = 1;
+        // threshold ladder (see PRE_VIDEOS).  Stage A needs no seed and runs for every bank size (a 32-video sample shard is
+        // just a stage A); a caller-provided seed (the multi-GPU sample) replaces it.  Stage B only pays off on a long rest.
+        const bool fast = k > 0 && vfr::fast_applicable(a);
+        const int na = (fast && !thr_seed) ? (Nv < vfr::PRE_VIDEOS ? Nv : vfr::PRE_VIDEOS) : 0;
+        // (after stage A's 32 videos an eighth of any rest >= 256 tightens a lot; after a seed -- normally the k-th key of a
+        // 256-video global sample -- only a stage B of >= 512 videos can tighten further)
+        const int nb = (fast && Nv - na >= (thr_seed ? 4096 : 256)) ? vfr::pre_b_videos(Nv - na) : 0;
+        if (k > 0 && !fast && !thr_seed && Nv <= 512) {
+            // generic shapes, small banks: ~10 videos per task for the cooperative-compaction kernel
             const int c = Nv / 10 < 1 ? 1 : Nv / 10;
             a.num_chunks = c < a.num_chunks ? c : a.num_chunks;
         }
-        if (stage_a) {
+        if (na > 0) {
             // one video per wave-task, threshold +inf: every moment of the sample goes to the merge, which selects the k
             // best (rank keys, when present, are counted in the same launch)
             vfr::ScoreArgs pre = a;
-            pre.v_lo = 0; pre.v_hi = vfr::PRE_VIDEOS; pre.num_chunks = vfr::PRE_CHUNKS;
+            pre.v_lo = 0; pre.v_hi = na; pre.num_chunks = na;
             pre.buf = w.buf_pre; pre.buf_cnt = w.cnt_pre; pre.keep_all = 1; pre.prof_site = vfr::SITE_SCORE_PREPASS;
             if (int rc = vfr::launch_score<1>(pre, kpl, st, &cap_pre)) return rc;
             {
                 vfr::ProfScope prof(vfr::SITE_TOPK_MERGE, st);
-                merge(w.buf_pre, w.cnt_pre, vfr::PRE_CHUNKS, cap_pre, nullptr, w.pre_keys, w.thr, nullptr, nullptr);
+                merge(w.buf_pre, w.cnt_pre, na, cap_pre, nullptr, w.pre_keys, w.thr, nullptr, nullptr);
             }
             VFR_CHECK_LAUNCH("topk_merge_tasks_kernel(A)");
             extra = w.pre_keys;
-            a.v_lo = vfr::PRE_VIDEOS;
+            a.v_lo = na;
         }
-        if (ladder) {
-            const int nb = vfr::pre_b_videos(Nv);
+        if (nb > 0) {
             vfr::ScoreArgs b = a;                       // same buffers as the main launch: the stream orders B, its merge, C
             b.v_hi = a.v_lo + nb;
             b.prof_site = vfr::SITE_SCORE_PREPASS;
