@@ -121,14 +121,17 @@ __device__ unsigned long long g_gemm_stamps[4];
 #define GSTAMP(i)
 #endif
 
-template <bool VEC, bool CONV, bool LSTM = false>
+// MI = 32-row MFMA tiles per wave along M: 2 -> 128-row workgroup tile, 1 -> 64-row tile (half the work per workgroup, for
+// launches whose 128-row grid would leave most of the chip idle or waiting on a second, nearly empty round)
+template <bool VEC, bool CONV, bool LSTM = false, int MI = 2>
 __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
-    // double-buffered tiles: [2][A 128x36 | W 128x36] floats = 73,728 B -> two workgroups per CU
-    __shared__ __attribute__((aligned(16))) float lds[VFR_GEMM_NBUF * (MBM + MBN) * MLD];
+    constexpr int TBM = 64 * MI, NA = 2 * MI;           // tile rows; float4 staging loads of A per thread (W: 4)
+    // double-buffered tiles: [2][A TBMx36 | W 128x36] floats (73,728 B at MI = 2) -> two workgroups per CU
+    __shared__ __attribute__((aligned(16))) float lds[VFR_GEMM_NBUF * (TBM + MBN) * MLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * MBM;
+    const int64_t m0 = (int64_t)blockIdx.x * TBM;
     const int n0 = blockIdx.y * MBN;
     // LSTM step with a shrinking / growing active prefix: rows past the active count do nothing this step
     const int64_t Mrows = (LSTM && g.lstm_mcount) ? (int64_t)g.lstm_mcount[g.lstm_step] : g.M;
@@ -138,21 +141,21 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #ifdef VFR_GEMM_STAMPS
     unsigned long long gst[4] = {0, 0, 0, 0}, gt0 = __builtin_amdgcn_s_memtime();
 #endif
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
     if (LSTM && g.lstm_tok) {
         // chains start from the vocabulary input-projection table: P[lstm_tok[row]][tile column].  Two batched load
         // rounds (all 32 table-row indices, then all 64 accumulators), not 32 dependent pairs one after the other.
-        int64_t prow[2][16];
+        int64_t prow[MI][16];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int64_t row = m0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 prow[mi][r] = (int64_t)g.lstm_tok[row < Mrows ? row : Mrows - 1];
             }
         const float *pcol = g.Cin + (int64_t)blockIdx.y * MBN + wn * 64 + l31;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[mi][0][r] = pcol[prow[mi][r] * g.ldc];
@@ -160,66 +163,72 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             }
     } else {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int64_t row = m0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int col = n0 + wn * 64 + ni * 32 + l31;
                 acc[mi][ni][r] = (g.Cin && row < g.M && col < g.N) ? g.Cin[row * g.ldc + col] : 0.0f;
             }
     }
 
-    float4 ra[4], rw[4];
+    float4 ra[NA], rw[4];
     // Staging loads.  Full K-tiles use UNCONDITIONAL loads (row index clamped into range; rows past M / N are
     // never stored) so the compiler can leave them in flight across the MFMA block -- a per-load bounds branch
     // makes hipcc drain vmcnt(0) right after issuing them.  Only the last, partial K-tile takes the guarded form.
-    const float *arow[4], *wrow[4], *arow2[4], *wrow2[4];
+    const float *arow[NA], *wrow[4], *arow2[NA], *wrow2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
-        const int64_t ma = m0 + row < Mrows ? m0 + row : Mrows - 1;
         int64_t nw = (int64_t)n0 + row < g.N ? (int64_t)n0 + row : g.N - 1;
         if (LSTM) {   // tile row R = (wn, ni, l31): gate = 2*ni + (l31 >> 4), unit = 32*blockIdx.y + 16*wn + (l31 & 15)
             const int gate = ((row >> 5) & 1) * 2 + ((row >> 4) & 1);
             int unit = blockIdx.y * 32 + (row >> 6) * 16 + (row & 15);
             unit = unit < g.lstm_H ? unit : g.lstm_H - 1;
             nw = (int64_t)gate * g.lstm_H + unit;
-            const int64_t hsrc = ma >= Mprev ? 0 : ma;             // a row joining now continues from the pad row's state
-            arow2[i] = g.A2 + hsrc * g.lda2 + kk;
             wrow2[i] = g.W2 + nw * g.ldw2 + kk;
         }
-        arow[i] = CONV ? g.A : g.A + ((LSTM && g.lstm_xrow) ? (int64_t)g.lstm_xrow[ma] : ma) * g.lda + kk;
         wrow[i] = g.W + nw * g.ldw + kk;
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
+        const int64_t ma = m0 + row < Mrows ? m0 + row : Mrows - 1;
+        if (LSTM) {
+            const int64_t hsrc = ma >= Mprev ? 0 : ma;             // a row joining now continues from the pad row's state
+            arow2[i] = g.A2 + hsrc * g.lda2 + kk;
+        }
+        arow[i] = CONV ? g.A : g.A + ((LSTM && g.lstm_xrow) ? (int64_t)g.lstm_xrow[ma] : ma) * g.lda + kk;
     }
     auto gload_full = [&](int k0) {
 #pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (VEC) ra[i] = *reinterpret_cast<const float4 *>(arow[i] + k0);
+            else     ra[i] = make_float4(arow[i][k0], arow[i][k0 + 1], arow[i][k0 + 2], arow[i][k0 + 3]);
+        }
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (VEC) {
-                ra[i] = *reinterpret_cast<const float4 *>(arow[i] + k0);
-                rw[i] = *reinterpret_cast<const float4 *>(wrow[i] + k0);
-            } else {
-                ra[i] = make_float4(arow[i][k0], arow[i][k0 + 1], arow[i][k0 + 2], arow[i][k0 + 3]);
-                rw[i] = make_float4(wrow[i][k0], wrow[i][k0 + 1], wrow[i][k0 + 2], wrow[i][k0 + 3]);
-            }
+            if (VEC) rw[i] = *reinterpret_cast<const float4 *>(wrow[i] + k0);
+            else     rw[i] = make_float4(wrow[i][k0], wrow[i][k0 + 1], wrow[i][k0 + 2], wrow[i][k0 + 3]);
         }
     };
     auto gload_tail = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
-            ra[i] = load4_guard<false>(g.A, g.lda, m0 + row, g.M, k0 + kk, g.K);
+            if (i < NA) ra[i] = load4_guard<false>(g.A, g.lda, m0 + row, g.M, k0 + kk, g.K);
             rw[i] = load4_guard<false>(g.W, g.ldw, (int64_t)n0 + row, g.N, k0 + kk, g.K);
         }
     };
     // ---- implicit-GEMM conv loader: per staged row the output pixel is fixed, per K-tile the thread's 4 consecutive
     // k's share one tap (conv_cin % 4 == 0); loads are unconditional from a clamped address, then zero-selected.
-    int cn[4], coy[4], cox[4];
-    bool crow_ok[4];
+    int cn[NA], coy[NA], cox[NA];
+    bool crow_ok[NA];
     if (CONV) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int f = tid + 256 * i, row = f >> 3;
             const int64_t p = m0 + row;
             crow_ok[i] = p < g.M;
@@ -237,12 +246,15 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         const int kc = kok ? k : 0;
         const int tap = kc / g.conv_cin, ci = kc - tap * g.conv_cin, ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int iy = coy[i] + ky - 1, ix = cox[i] + kx - 1;
             const bool ok = kok && crow_ok[i] && iy >= 0 && iy < g.conv_h && ix >= 0 && ix < g.conv_w;
             const int64_t off = ok ? (((int64_t)cn[i] * g.conv_h + iy) * g.conv_w + ix) * g.conv_cin + ci : 0;
             const float4 v = *reinterpret_cast<const float4 *>(g.A + off);
             ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             const float4 wv = *reinterpret_cast<const float4 *>(wrow[i] - kk + kc);     // row clamped, k clamped
             rw[i] = kok ? wv : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -257,61 +269,68 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         const bool kok = k < (second ? g.K2 : g.K);
         const int kc = kok ? k : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const float *ap = (second ? arow2[i] : arow[i]) - kk + kc;
-            const float *wp = (second ? wrow2[i] : wrow[i]) - kk + kc;
             const float4 av = *reinterpret_cast<const float4 *>(ap);
-            const float4 wv = *reinterpret_cast<const float4 *>(wp);
             ra[i] = kok ? av : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *wp = (second ? wrow2[i] : wrow[i]) - kk + kc;
+            const float4 wv = *reinterpret_cast<const float4 *>(wp);
             rw[i] = kok ? wv : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     const int nk_full = LSTM ? nk1 + (g.K2 + MBK - 1) / MBK
                              : CONV ? (g.K + MBK - 1) / MBK : g.K / MBK;     // conv / lstm: every tile through a select loader
     auto swrite = [&](int b) {
-        float *As = lds + b * (MBM + MBN) * MLD, *Ws = As + MBM * MLD;
+        float *As = lds + b * (TBM + MBN) * MLD, *Ws = As + TBM * MLD;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
-            *reinterpret_cast<float4 *>(&As[row * MLD + kk]) = ra[i];
+            if (i < NA) *reinterpret_cast<float4 *>(&As[row * MLD + kk]) = ra[i];
             *reinterpret_cast<float4 *>(&Ws[row * MLD + kk]) = rw[i];
         }
     };
     auto compute = [&](int b) {
-        const float *As = lds + b * (MBM + MBN) * MLD, *Ws = As + MBM * MLD;
-        const float *ap = &As[(wm * 64 + l31) * MLD];
+        const float *As = lds + b * (TBM + MBN) * MLD, *Ws = As + TBM * MLD;
+        const float *ap = &As[(wm * (32 * MI) + l31) * MLD];
         const float *wp = &Ws[(wn * 64 + l31) * MLD];
         // fragment double buffer: the four ds_read_b128 of slice k4+1 are issued (and pinned) BEFORE the eight MFMAs
         // of slice k4, so their latency hides under the matrix pipe instead of sitting between MFMA groups
-        float4 fa[2][2], fb[2][2];
-        fa[0][0] = *reinterpret_cast<const float4 *>(ap);
-        fa[0][1] = *reinterpret_cast<const float4 *>(ap + 32 * MLD);
+        float4 fa[2][MI], fb[2][2];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fa[0][mi] = *reinterpret_cast<const float4 *>(ap + mi * 32 * MLD);
         fb[0][0] = *reinterpret_cast<const float4 *>(wp);
         fb[0][1] = *reinterpret_cast<const float4 *>(wp + 32 * MLD);
 #pragma unroll
         for (int k4 = 0; k4 < MBK / 4; ++k4) {
             const int cur = k4 & 1, nxt = cur ^ 1;
             if (k4 + 1 < MBK / 4) {
-                fa[nxt][0] = *reinterpret_cast<const float4 *>(ap + (k4 + 1) * 4);
-                fa[nxt][1] = *reinterpret_cast<const float4 *>(ap + 32 * MLD + (k4 + 1) * 4);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) fa[nxt][mi] = *reinterpret_cast<const float4 *>(ap + mi * 32 * MLD + (k4 + 1) * 4);
                 fb[nxt][0] = *reinterpret_cast<const float4 *>(wp + (k4 + 1) * 4);
                 fb[nxt][1] = *reinterpret_cast<const float4 *>(wp + 32 * MLD + (k4 + 1) * 4);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const float4 a0 = fa[cur][0], a1 = fa[cur][1], b0 = fb[cur][0], b1 = fb[cur][1];
+            const float4 b0 = fb[cur][0], b1 = fb[cur][1];
             {   // k = 4*k4 + h
-                const float fa0 = h ? a0.y : a0.x, fa1 = h ? a1.y : a1.x, fb0 = h ? b0.y : b0.x, fb1 = h ? b1.y : b1.x;
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc[1][1], 0, 0, 0);
+                const float fb0 = h ? b0.y : b0.x, fb1 = h ? b1.y : b1.x;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const float fam = h ? fa[cur][mi].y : fa[cur][mi].x;
+                    acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fam, fb0, acc[mi][0], 0, 0, 0);
+                    acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fam, fb1, acc[mi][1], 0, 0, 0);
+                }
             }
             {   // k = 4*k4 + 2 + h
-                const float fa0 = h ? a0.w : a0.z, fa1 = h ? a1.w : a1.z, fb0 = h ? b0.w : b0.z, fb1 = h ? b1.w : b1.z;
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc[1][1], 0, 0, 0);
+                const float fb0 = h ? b0.w : b0.z, fb1 = h ? b1.w : b1.z;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const float fam = h ? fa[cur][mi].w : fa[cur][mi].z;
+                    acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fam, fb0, acc[mi][0], 0, 0, 0);
+                    acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fam, fb1, acc[mi][1], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -359,14 +378,14 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         // item (mi, j): row r = 2j + hi_lane.  Everything is branch-free and batched: 16 previous-cell loads up front (clamped
         // addresses), 32 exchanges (each lane sends only the half its partner finishes), 16 independent gate evaluations the
         // scheduler can interleave, predicated stores last.
-        float cprev[2][8], xi[2][8], xf[2][8], xg[2][8], xo[2][8];
-        int64_t orow[2][8];
+        float cprev[MI][8], xi[MI][8], xf[MI][8], xg[MI][8], xo[MI][8];
+        int64_t orow[MI][8];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r0 = 2 * j, r1 = 2 * j + 1;
-                const int64_t rowe = m0 + wm * 64 + mi * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * h;     // r1's row = rowe + 1
+                const int64_t rowe = m0 + wm * (32 * MI) + mi * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * h;     // r1's row = rowe + 1
                 const int64_t row = rowe + (hi_lane ? 1 : 0);
                 orow[mi][j] = row;
                 const int64_t rc = row < Mrows ? row : Mrows - 1;
@@ -378,7 +397,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 xg[mi][j] = hi_lane ? p1 : own1; xo[mi][j] = hi_lane ? own1 : p1;
             }
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float ig = c_sigmoidf(xi[mi][j] + bi);
@@ -400,7 +419,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         return;
     }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int col = n0 + wn * 64 + ni * 32 + l31;
@@ -413,7 +432,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 const float w0 = g.vis_w0[col], w1 = g.vis_w1[col], b = g.bias[col];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int64_t row = m0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (row >= g.M) continue;
                     const float te0 = g.vis_te[2 * row], te1 = g.vis_te[2 * row + 1];
                     const float te = __builtin_fmaf(te1, w1, __builtin_fmaf(te0, w0, 0.0f));
@@ -424,7 +443,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int64_t row = m0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row >= g.M) continue;
                 float v = acc[mi][ni][r];
                 if (g.epi & (EPI_BIAS | EPI_BIAS2)) v = v + badd;
@@ -442,7 +461,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp) { gemm_
 
 __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true>(g); }
 
-__global__ __launch_bounds__(256, 2) void lstm_step_mfma_pair(GemmPair gp) { gemm_nt_mfma_body<true, false, true>(gp.p[blockIdx.z]); }
+template <int MI>
+__global__ __launch_bounds__(256, 2) void lstm_step_mfma_pair(GemmPair gp) { gemm_nt_mfma_body<true, false, true, MI>(gp.p[blockIdx.z]); }
 
 __global__ __launch_bounds__(256) void repack_rows_kernel(const float *__restrict__ src, int64_t ld_src, int rows, int cols,
                                                           float *__restrict__ dst)
@@ -504,8 +524,16 @@ int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
     }
     ProfScope prof(g0.site, st);
     GemmPair gp{{g0, g1}};
-    dim3 grid((unsigned)cdiv(g0.M, MBM), (unsigned)cdiv(g0.lstm_H, 32), 2);
-    hipLaunchKernelGGL(lstm_step_mfma_pair, grid, dim3(256), 0, st, gp);
+    // 64-row tiles when the 128-row grid would not even fill the chip's 512 workgroup slots 1.5 times: the step is then a
+    // tile's latency, and half-size tiles spread the same work over twice as many waves
+    const int64_t wgs128 = cdiv(g0.M, MBM) * cdiv(g0.lstm_H, 32) * 2;
+    if (opt_lstm_tile() == 1 || (opt_lstm_tile() == 0 && wgs128 < 768)) {
+        dim3 grid((unsigned)cdiv(g0.M, 64), (unsigned)cdiv(g0.lstm_H, 32), 2);
+        hipLaunchKernelGGL(lstm_step_mfma_pair<1>, grid, dim3(256), 0, st, gp);
+    } else {
+        dim3 grid((unsigned)cdiv(g0.M, MBM), (unsigned)cdiv(g0.lstm_H, 32), 2);
+        hipLaunchKernelGGL(lstm_step_mfma_pair<2>, grid, dim3(256), 0, st, gp);
+    }
     VFR_CHECK_LAUNCH("lstm_step_mfma_pair");
 #ifdef VFR_GEMM_STAMPS
     if (g0.lstm_step == 19 || g0.lstm_step == 0) {

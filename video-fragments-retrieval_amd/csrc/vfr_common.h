@@ -19,6 +19,7 @@ inline hipStream_t as_stream(vfr_stream_t s) { return reinterpret_cast<hipStream
 int opt_gemm();
 int opt_score_fast();
 int opt_score_split();
+int opt_lstm_tile();
 
 // ---- launch-site profiler (vfr_set_option("profile", 1)): HIP events recorded on the launch stream
 // around every instrumented launch; vfr_profile_read() turns them into per-site totals after a sync.
