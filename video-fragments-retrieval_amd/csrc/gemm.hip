@@ -453,8 +453,8 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         }
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(256, VFR_GEMM_NBUF == 1 ? 3 : 2) void gemm_nt_mfma(GemmArgs g) { gemm_nt_mfma_body<VEC, false>(g); }
+template <bool VEC, int MI = 2>
+__global__ __launch_bounds__(256, VFR_GEMM_NBUF == 1 ? 3 : 2) void gemm_nt_mfma(GemmArgs g) { gemm_nt_mfma_body<VEC, false, false, MI>(g); }
 
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp) { gemm_nt_mfma_body<VEC, false>(gp.p[blockIdx.z]); }
@@ -588,6 +588,14 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
         return VFR_OK;
     }
     const bool vec = gemm_vec_ok(g);
+    if ((int64_t)grid.x * grid.y < 384) {
+        // fewer workgroups than 1.5 per CU: the launch is one tile's latency, so halve the tile (64 rows)
+        dim3 grid64((unsigned)cdiv(g.M, 64), grid.y);
+        if (vec) hipLaunchKernelGGL((gemm_nt_mfma<true, 1>), grid64, dim3(256), 0, st, g);
+        else     hipLaunchKernelGGL((gemm_nt_mfma<false, 1>), grid64, dim3(256), 0, st, g);
+        VFR_CHECK_LAUNCH("gemm_nt_mfma<64>");
+        return VFR_OK;
+    }
     if (vec) hipLaunchKernelGGL(gemm_nt_mfma<true>, grid, dim3(256), 0, st, g);
     else     hipLaunchKernelGGL(gemm_nt_mfma<false>, grid, dim3(256), 0, st, g);
     VFR_CHECK_LAUNCH("gemm_nt_mfma");

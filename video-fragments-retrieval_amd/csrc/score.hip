@@ -182,6 +182,7 @@ struct ScoreArgs {
     int force_generic;                                // 1: use score_kernel (cooperative compaction) even if fast applies
     int prof_site;                                    // profiler site of this launch (0: chosen from the mode)
     int keep_all;                                     // 1: hand every appended key to the merge (no final per-column cut)
+    int level_cap;                                    // > 0: only moments of at most this many clips are appended (stage A)
 #ifdef VFR_SCORE_STAMPS
     unsigned long long *stamps;                       // debug build: per-phase s_memtime totals of the fused kernel
 #endif
@@ -639,7 +640,7 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
             // left-to-right sums -- with the exact score, key and append
 #pragma unroll
             for (int L = 1; L <= NT; ++L) {
-                if ((lvl >> (NT - L)) & 1u) {
+                if (((lvl >> (NT - L)) & 1u) && (a.level_cap == 0 || L <= a.level_cap)) {
                     const unsigned hx = hix_t[L - 1];
 #pragma nounroll
                     for (int s = 0; s + L <= n; ++s) {
@@ -727,7 +728,7 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
                                                                unsigned long long *__restrict__ out_keys,
                                                                unsigned long long *__restrict__ thr_seed,
                                                                float *__restrict__ out_dist,
-                                                               int64_t *__restrict__ out_idx)
+                                                               int64_t *__restrict__ out_idx, int seed_inclusive)
 {
     constexpr int CAP = KPL * 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -802,8 +803,13 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
         if (e < k) {
             const bool ok = key[i] != KEY_MAX;
             if (out_keys) out_keys[q * k + e] = key[i];
-            // k-th best so far (KEY_MAX if fewer): only ever tightens the stored threshold (it may hold a caller's seed)
-            if (thr_seed && e == k - 1 && key[i] < thr_seed[q]) thr_seed[q] = key[i];
+            // k-th best so far (KEY_MAX if fewer): only ever tightens the stored threshold (it may hold a caller's seed).
+            // seed_inclusive: the keys merged here will be scored AGAIN under the seed (the kernels keep key < seed), so
+            // the k-th key itself must still pass
+            if (thr_seed && e == k - 1) {
+                const unsigned long long t = (seed_inclusive && key[i] != KEY_MAX) ? key[i] + 1ull : key[i];
+                if (t < thr_seed[q]) thr_seed[q] = t;
+            }
             if (out_dist) {
                 out_dist[q * k + e] = ok ? __uint_as_float((unsigned)(key[i] >> 32)) : __builtin_inff();
                 out_idx[q * k + e] = ok ? (int64_t)(key[i] & 0xffffffffull) : -1;
@@ -907,15 +913,17 @@ static void plan_tasks(int64_t Nq, int Nv, int *groups, int *chunks)
 }
 static int kpl_for(int k) { return k <= 128 ? 4 : 8; }
 
-// Threshold ladder of the top-k pass (k > 0, fast path, corpus large enough).  The fused kernel appends every moment that
-// beats the query's current threshold, so the threshold's quality decides how often its exact path runs:
-//   stage A  the first PRE_VIDEOS videos, one per wave-task, scored exactly by the cooperative-sort kernel -> their k-th key
-//   stage B  the next pre_b_videos() videos with the fused kernel under A's threshold -> merged with A: the k-th key of
-//            ~Nv/8 videos, which admits ~8k candidates per query in ...
+// Threshold ladder of the top-k pass (k > 0, fast path).  The fused kernel appends every moment that beats the query's
+// current threshold, so the threshold's quality decides how often its exact path runs:
+//   stage A  the short moments (<= PRE_LEVELS clips) of the first PRE_VIDEOS videos, one video per wave-task, threshold
+//            +inf -> merge -> their k-th key: a valid (any k keys bound the k-th best) and already tight bound, for 0.4 ms;
+//   stage B  the first pre_b_videos() videos (the sample included) under A's threshold -> merge: the k-th key of ~Nv/8
+//            videos, which admits only ~8k candidates per query in ...
 //   stage C  ... the rest of the corpus (the main launch); the final merge takes B's merged list as its `extra` input.
-// Every stage scores its own videos once; only the merges (0.3 ms) are added work.
+// Every video's full moment set is scored exactly once (stage A's partial pass over 32 videos is the only repeated work).
 constexpr int PRE_VIDEOS = 32;
 constexpr int PRE_CHUNKS = 32;
+constexpr int PRE_LEVELS = 4;       // stage A keeps moments of at most this many clips
 static int pre_b_videos(int Nv) { const int b = Nv / 8; return b > 1024 ? 1024 : b; }
 
 struct TopkWs { unsigned long long *buf, *buf_pre, *pre_keys, *pre_keys2; int *cnt, *cnt_pre; unsigned long long *thr; size_t total; };
@@ -1074,14 +1082,14 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
     int cap_t = 0, cap_pre = 0;
     const unsigned long long *extra = nullptr;
     auto merge = [&](const unsigned long long *buf, const int *cnt, int chunks, int capt, const unsigned long long *ex,
-                     unsigned long long *okeys, unsigned long long *seed, float *od, int64_t *oi) {
+                     unsigned long long *okeys, unsigned long long *seed, float *od, int64_t *oi, int seed_incl = 0) {
         dim3 grid((unsigned)vfr::cdiv(Nq, 4)), block(256);
         if (kpl == 4)
             hipLaunchKernelGGL((vfr::topk_merge_tasks_kernel<4>), grid, block, 0, st, buf, cnt, a.num_groups, chunks, Nq, k,
-                               capt, ex, okeys, seed, od, oi);
+                               capt, ex, okeys, seed, od, oi, seed_incl);
         else
             hipLaunchKernelGGL((vfr::topk_merge_tasks_kernel<8>), grid, block, 0, st, buf, cnt, a.num_groups, chunks, Nq, k,
-                               capt, ex, okeys, seed, od, oi);
+                               capt, ex, okeys, seed, od, oi, seed_incl);
     };
     if (Nv > 0) {
         if (k > 0) {
@@ -1093,28 +1101,29 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
         // just a stage A); a caller-provided seed (the multi-GPU sample) replaces it.  Stage B only pays off on a long rest.
         const bool fast = k > 0 && vfr::fast_applicable(a);
         const int na = (fast && !thr_seed) ? (Nv < vfr::PRE_VIDEOS ? Nv : vfr::PRE_VIDEOS) : 0;
-        // (after stage A's 32 videos an eighth of any rest >= 256 tightens a lot; after a seed -- normally the k-th key of a
-        // 256-video global sample -- only a stage B of >= 512 videos can tighten further)
-        const int nb = (fast && Nv - na >= (thr_seed ? 4096 : 256)) ? vfr::pre_b_videos(Nv - na) : 0;
+        // (after stage A's 32 videos an eighth of any corpus >= 256 tightens a lot; after a seed -- normally the k-th key of
+        // a 256-video global sample -- only a stage B of >= 512 videos can tighten further)
+        const int nb = (fast && Nv >= (thr_seed ? 4096 : 256)) ? vfr::pre_b_videos(Nv) : 0;
         if (k > 0 && !fast && !thr_seed && Nv <= 512) {
             // generic shapes, small banks: ~10 videos per task for the cooperative-compaction kernel
             const int c = Nv / 10 < 1 ? 1 : Nv / 10;
             a.num_chunks = c < a.num_chunks ? c : a.num_chunks;
         }
         if (na > 0) {
-            // one video per wave-task, threshold +inf: every moment of the sample goes to the merge, which selects the k
-            // best (rank keys, when present, are counted in the same launch)
+            // Stage A only has to produce a VALID threshold cheaply: one video per wave-task, threshold +inf, and only the
+            // moments of <= PRE_LEVELS clips are kept (the best moments are short ones, and any k keys bound the k-th
+            // best from above); the merge's k-th key (+1: inclusive) becomes every query's threshold.  The sample videos
+            // are then scored like all others by the next stage, so nothing here needs rank keys or an output list.
             vfr::ScoreArgs pre = a;
-            pre.v_lo = 0; pre.v_hi = na; pre.num_chunks = na;
-            pre.buf = w.buf_pre; pre.buf_cnt = w.cnt_pre; pre.keep_all = 1; pre.prof_site = vfr::SITE_SCORE_PREPASS;
+            pre.v_lo = 0; pre.v_hi = na; pre.num_chunks = na; pre.num_rank = 0; pre.rank_dist = nullptr; pre.rank_idx = nullptr;
+            pre.buf = w.buf_pre; pre.buf_cnt = w.cnt_pre; pre.keep_all = 1; pre.level_cap = vfr::PRE_LEVELS;
+            pre.prof_site = vfr::SITE_SCORE_PREPASS;
             if (int rc = vfr::launch_score<1>(pre, kpl, st, &cap_pre)) return rc;
             {
                 vfr::ProfScope prof(vfr::SITE_TOPK_MERGE, st);
-                merge(w.buf_pre, w.cnt_pre, na, cap_pre, nullptr, w.pre_keys, w.thr, nullptr, nullptr);
+                merge(w.buf_pre, w.cnt_pre, na, cap_pre, nullptr, nullptr, w.thr, nullptr, nullptr, 1);
             }
             VFR_CHECK_LAUNCH("topk_merge_tasks_kernel(A)");
-            extra = w.pre_keys;
-            a.v_lo = na;
         }
         if (nb > 0) {
             vfr::ScoreArgs b = a;                       // same buffers as the main launch: the stream orders B, its merge, C
