@@ -109,13 +109,14 @@ __global__ __launch_bounds__(SORT_BLOCK) void sort_rows_kernel(const int *__rest
     xrow[pos + 1] = (int)b;
 }
 
-// mcount[s] = 1 + #{b : len[b] > T-1-s}: active rows of the reverse direction at step s
-__global__ void active_rows_kernel(const int *__restrict__ len, int64_t B, int T, int *__restrict__ mcount)
+// mcount[s] = 1 + #{b : len[b] > T-1-s}: active rows of the reverse direction at step s (from the per-block histograms)
+__global__ void active_rows_kernel(const int *__restrict__ hist, int nblk, int T, int *__restrict__ mcount)
 {
     const int s = threadIdx.x;
     if (s >= T) return;
     int c = 1;
-    for (int64_t b = 0; b < B; ++b) c += len[b] > T - 1 - s ? 1 : 0;
+    for (int k = 0; k < nblk; ++k)
+        for (int l = T - s; l <= T; ++l) c += hist[(size_t)k * (T + 1) + l];
     mcount[s] = c;
 }
 
@@ -240,7 +241,8 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
                        w.len, B, T, w.hist);
     hipLaunchKernelGGL(vfr::sort_rows_kernel, dim3((unsigned)vfr::cdiv(B, vfr::SORT_BLOCK)), dim3(vfr::SORT_BLOCK), 0, st,
                        w.len, w.hist, B, T, w.row_of, w.xrow);
-    hipLaunchKernelGGL(vfr::active_rows_kernel, dim3(1), dim3(T < 64 ? 64 : T), 0, st, w.len, B, T, w.mcount);
+    hipLaunchKernelGGL(vfr::active_rows_kernel, dim3(1), dim3(T < 64 ? 64 : T), 0, st, w.hist, (int)vfr::cdiv(B, vfr::SORT_BLOCK), T,
+                       w.mcount);
     }
     VFR_CHECK_LAUNCH("bilstm row bookkeeping");
     float *h_sorted = w.hcat;

@@ -881,12 +881,24 @@ __global__ __launch_bounds__(64) void score_own_kernel(const float *__restrict__
     const int64_t q = (int64_t)blockIdx.x * 64 + lane;
     if (q >= Nq) return;
     const int v = own[q], c0 = clip_off[v], n = clip_off[v + 1] - c0;
-    for (int m = 0; m < Mmax; ++m) scores[q * Mmax + m] = __builtin_inff();
+    for (int m = n * (n + 1) / 2; m < Mmax; ++m) scores[q * Mmax + m] = __builtin_inff();   // slots past this video's moments
+    const bool vec = (D & 3) == 0 && ((((uintptr_t)V) | ((uintptr_t)Q)) & 15) == 0;
     for (int c = 0; c < n; ++c) {
         float acc = 0.0f;
-        for (int k = 0; k < D; ++k) {
-            float d = (V[(int64_t)(c0 + c) * D + k] - Q[q * D + k]) + eps;
-            acc = __builtin_fmaf(d, d, acc);
+        const float *vr = V + (int64_t)(c0 + c) * D, *qr = Q + q * D;
+        if (vec) {                                       // same k-ascending chain, 16-byte loads
+            for (int k = 0; k < D; k += 4) {
+                const float4 a = *reinterpret_cast<const float4 *>(vr + k), b = *reinterpret_cast<const float4 *>(qr + k);
+                float d = (a.x - b.x) + eps; acc = __builtin_fmaf(d, d, acc);
+                d = (a.y - b.y) + eps; acc = __builtin_fmaf(d, d, acc);
+                d = (a.z - b.z) + eps; acc = __builtin_fmaf(d, d, acc);
+                d = (a.w - b.w) + eps; acc = __builtin_fmaf(d, d, acc);
+            }
+        } else {
+            for (int k = 0; k < D; ++k) {
+                float d = (vr[k] - qr[k]) + eps;
+                acc = __builtin_fmaf(d, d, acc);
+            }
         }
         ds[c * 64 + lane] = __builtin_sqrtf(acc);
     }
