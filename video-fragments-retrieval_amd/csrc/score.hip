@@ -636,18 +636,32 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
         }
         STAMP(3)
         if (TOPK && lvl != 0) {
-            // some moment may enter the top-k: re-walk the flagged levels from the LDS distance column -- the same
-            // left-to-right sums -- with the exact score, key and append
+            // Some moment may enter the top-k.  Two phases per flagged level, so that the common work stays in registers:
+            // (1) the level's sums again from the 21 distances (one LDS burst for all levels; the same left-to-right sums)
+            // -> a per-lane bit mask of the moments under the bound; (2) only those (usually one) are popped: exact score,
+            // key, append.
+            float dd[NT];
+#pragma unroll
+            for (int c = 0; c < NT; ++c) dd[c] = (EXACT || c < n) ? ds[c * 64 + lane] : __builtin_inff();
 #pragma unroll
             for (int L = 1; L <= NT; ++L) {
                 if (((lvl >> (NT - L)) & 1u) && (a.level_cap == 0 || L <= a.level_cap)) {
                     const unsigned hx = hix_t[L - 1];
+                    unsigned pm = 0;
+#pragma unroll
+                    for (int s = 0; s + L <= NT; ++s) {
+                        float sum = dd[s];
+#pragma unroll
+                        for (int e = s + 1; e < s + L; ++e) sum += dd[e];
+                        pm |= (__float_as_uint(sum) < hx ? 1u : 0u) << s;
+                    }
+                    while (pm) {
+                        const int s = __builtin_ctz(pm);
+                        pm &= pm - 1u;
+                        if (s + L <= n) {                // (+inf padding can pass only while the bound is still +inf)
+                            float sum = ds[s * 64 + lane];
 #pragma nounroll
-                    for (int s = 0; s + L <= n; ++s) {
-                        float sum = ds[s * 64 + lane];
-#pragma nounroll
-                        for (int e = s + 1; e < s + L; ++e) sum += ds[e * 64 + lane];
-                        if (__float_as_uint(sum) < hx) {
+                            for (int e = s + 1; e < s + L; ++e) sum += ds[e * 64 + lane];
                             const float sc = sum / (float)L;
                             const unsigned id = (unsigned)(a.id_base + mbase + moment_index(n, s, s + L - 1));
                             const unsigned long long key = make_key(sc, id);
