@@ -428,16 +428,23 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             if (g.epi & EPI_BIAS2) badd = g.bias[col] + g.bias2[col];
             else if (g.epi & EPI_BIAS) badd = g.bias[col];
             if (g.epi & EPI_VIS) {
-                // hidden layer of the clip encoder fused here: the S array never exists in HBM
+                // hidden layer of the clip encoder fused here: the S array never exists in HBM.  Loads first (clamped
+                // rows, no branches), then the arithmetic, then predicated stores.
                 const float w0 = g.vis_w0[col], w1 = g.vis_w1[col], b = g.bias[col];
+                float cx[16], t0[16], t1[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t row = m0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row >= g.M) continue;
-                    const float te0 = g.vis_te[2 * row], te1 = g.vis_te[2 * row + 1];
-                    const float te = __builtin_fmaf(te1, w1, __builtin_fmaf(te0, w0, 0.0f));
-                    const float x = ((acc[mi][ni][r] + g.vis_cx[(int64_t)g.vis_row[row] * g.N + col]) + te) + b;
-                    g.out[row * g.ldo + col] = x > 0.0f ? x : 0.0f;
+                    const int64_t rc = row < g.M ? row : g.M - 1;
+                    t0[r] = g.vis_te[2 * rc]; t1[r] = g.vis_te[2 * rc + 1];
+                    cx[r] = g.vis_cx[(int64_t)g.vis_row[rc] * g.N + col];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float te = __builtin_fmaf(t1[r], w1, __builtin_fmaf(t0[r], w0, 0.0f));
+                    const float x = ((acc[mi][ni][r] + cx[r]) + te) + b;
+                    if (row < g.M) g.out[row * g.ldo + col] = x > 0.0f ? x : 0.0f;
                 }
                 continue;
             }
