@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 SITE_OF = (("lstm_step_mfma_pair", "gemm_lstm_rec"), ("score_fast_kernel<21", "score_fused"), ("score_fast_kernel<6", "score_fused"),
-           ("segment_pool_norm", "pool"), ("topk_merge", "topk_merge"), ("gemm_nt_mfma<true>", "gemm_vis_seg"))
+           ("segment_pool_norm", "pool"), ("topk_merge", "topk_merge"), ("gemm_nt_mfma<true, 2>", "gemm_vis_seg"))
 
 
 def per_kernel(folder, counter):

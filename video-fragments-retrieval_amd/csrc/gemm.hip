@@ -131,8 +131,14 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     __shared__ __attribute__((aligned(16))) float lds[VFR_GEMM_NBUF * (TBM + MBN) * MLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * TBM;
-    const int n0 = blockIdx.y * MBN;
+    int64_t m0 = (int64_t)blockIdx.x * TBM;
+    int n0 = blockIdx.y * MBN;
+    if (!CONV && !LSTM && g.xcd_cols > 0) {
+        const unsigned L = blockIdx.x, per = 8u * (unsigned)g.xcd_cols, within = L % per;
+        m0 = ((int64_t)(L / per) * 8 + (within & 7u)) * TBM;
+        n0 = (int)(within >> 3) * MBN;
+        if (m0 >= g.M) return;                           // grid padded to whole groups of 8 row tiles
+    }
     // LSTM step with a shrinking / growing active prefix: rows past the active count do nothing this step
     const int64_t Mrows = (LSTM && g.lstm_mcount) ? (int64_t)g.lstm_mcount[g.lstm_step] : g.M;
     const int64_t Mprev = (LSTM && g.lstm_mcount) ? (g.lstm_step > 0 ? (int64_t)g.lstm_mcount[g.lstm_step - 1] : 1) : Mrows;
@@ -601,6 +607,16 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
         if (vec) hipLaunchKernelGGL((gemm_nt_mfma<true, 1>), grid64, dim3(256), 0, st, g);
         else     hipLaunchKernelGGL((gemm_nt_mfma<false, 1>), grid64, dim3(256), 0, st, g);
         VFR_CHECK_LAUNCH("gemm_nt_mfma<64>");
+        return VFR_OK;
+    }
+    if (grid.y > 1 && grid.y <= 16 && grid.x >= 64) {
+        // tall GEMM with a few column tiles (the clip encoder's seg x W1: 1641 x 4): XCD-aware tile order, see xcd_cols
+        GemmArgs gx = g;
+        gx.xcd_cols = (int)grid.y;
+        dim3 grid1((unsigned)(cdiv(grid.x, 8) * 8 * grid.y));
+        if (vec) hipLaunchKernelGGL(gemm_nt_mfma<true>, grid1, dim3(256), 0, st, gx);
+        else     hipLaunchKernelGGL(gemm_nt_mfma<false>, grid1, dim3(256), 0, st, gx);
+        VFR_CHECK_LAUNCH("gemm_nt_mfma(xcd)");
         return VFR_OK;
     }
     if (vec) hipLaunchKernelGGL(gemm_nt_mfma<true>, grid, dim3(256), 0, st, g);

@@ -72,6 +72,10 @@ struct GemmArgs {
     int64_t M; int N; int K;
     int epi;
     int site;                          // profiler site (SITE_NONE = not instrumented)
+    // xcd_cols > 0 (dense MFMA kernel, set by gemm_nt): 1-D grid; workgroup L computes row tile (L / (8*xcd_cols))*8 + L % 8
+    // and column tile (L / 8) % xcd_cols, so the xcd_cols column tiles that share an A row tile are dispatched 8 apart --
+    // onto the SAME XCD (workgroups go round-robin over the 8 XCDs) -- and A streams from HBM once, not once per column tile
+    int xcd_cols;
     // EPI_VIS (MFMA kernel only): vis_row[m] = video of clip row m, vis_te[m] = (t/n, (t+1)/n), vis_cx [videos, N] = the
     // per-video context chains, vis_w0 / vis_w1 [N] = the two temporal-endpoint weight columns
     const int *vis_row; const float *vis_te; const float *vis_cx; const float *vis_w0, *vis_w1;
