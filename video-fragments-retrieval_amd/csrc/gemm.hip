@@ -396,8 +396,12 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 orow[mi][j] = row;
                 const int64_t rc = row < Mrows ? row : Mrows - 1;
                 cprev[mi][j] = g.lstm_cin[(rc >= Mprev ? 0 : rc) * H + uc];
-                const float own0 = hi_lane ? acc[mi][0][r1] : acc[mi][0][r0], own1 = hi_lane ? acc[mi][1][r1] : acc[mi][1][r0];
-                const float snd0 = hi_lane ? acc[mi][0][r0] : acc[mi][0][r1], snd1 = hi_lane ? acc[mi][1][r0] : acc[mi][1][r1];
+                // (the four accumulators go through an empty asm first: otherwise LLVM folds "c ? v[r1] : v[r0]" into a
+                // DYNAMIC vector index v[c ? r1 : r0], which it then lowers to a 16-way compare/select chain per extract)
+                float e00 = acc[mi][0][r0], e01 = acc[mi][0][r1], e10 = acc[mi][1][r0], e11 = acc[mi][1][r1];
+                asm volatile("" : "+v"(e00), "+v"(e01), "+v"(e10), "+v"(e11));
+                const float own0 = hi_lane ? e01 : e00, own1 = hi_lane ? e11 : e10;
+                const float snd0 = hi_lane ? e00 : e01, snd1 = hi_lane ? e10 : e11;
                 const float p0 = __shfl_xor(snd0, 16, 64), p1 = __shfl_xor(snd1, 16, 64);
                 xi[mi][j] = hi_lane ? p0 : own0; xf[mi][j] = hi_lane ? own0 : p0;
                 xg[mi][j] = hi_lane ? p1 : own1; xo[mi][j] = hi_lane ? own1 : p1;
