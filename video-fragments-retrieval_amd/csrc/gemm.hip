@@ -406,6 +406,9 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 xi[mi][j] = hi_lane ? p0 : own0; xf[mi][j] = hi_lane ? own0 : p0;
                 xg[mi][j] = hi_lane ? p1 : own1; xo[mi][j] = hi_lane ? own1 : p1;
             }
+        // all cells in ONE basic block (the asm pins the results ahead of the predicated stores; hipcc otherwise sinks each
+        // cell's ~190 instructions into its own store predicate, one serial dependency chain after the other)
+        float cnew[MI][8], hnew[MI][8];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -414,13 +417,18 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 const float fg = c_sigmoidf(xf[mi][j] + bf);
                 const float gg = c_tanhf(xg[mi][j] + bg);
                 const float og = c_sigmoidf(xo[mi][j] + bo);
-                const float cn = __builtin_fmaf(fg, cprev[mi][j], ig * gg);
-                const float hn = og * c_tanhf(cn);
-                if (valid && orow[mi][j] < Mrows) {
-                    g.lstm_c[orow[mi][j] * H + unit] = cn;
-                    g.lstm_h[orow[mi][j] * g.lstm_ldh + unit] = hn;
-                }
+                cnew[mi][j] = __builtin_fmaf(fg, cprev[mi][j], ig * gg);
+                hnew[mi][j] = og * c_tanhf(cnew[mi][j]);
+                asm volatile("" : "+v"(cnew[mi][j]), "+v"(hnew[mi][j]));
             }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (valid && orow[mi][j] < Mrows) {
+                    g.lstm_c[orow[mi][j] * H + unit] = cnew[mi][j];
+                    g.lstm_h[orow[mi][j] * g.lstm_ldh + unit] = hnew[mi][j];
+                }
         GSTAMP(2)
 #ifdef VFR_GEMM_STAMPS
         if (lane == 0) for (int i = 0; i < 3; ++i) atomicAdd(&g_gemm_stamps[i], gst[i]);
