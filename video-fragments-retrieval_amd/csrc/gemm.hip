@@ -181,6 +181,12 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     }
 
     float4 ra[NA], rw[4];
+    // Zero-fill of staged elements outside the operand (conv padding taps, the tail of a segmented K) is decided when the
+    // load is ISSUED but applied when the registers are written to LDS: a select right after the load would make hipcc
+    // wait for the load (vmcnt(0)) before the MFMA block and expose its latency in every K-tile.
+    bool za[NA], zw = false;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) za[i] = false;
     // Staging loads.  Full K-tiles use UNCONDITIONAL loads (row index clamped into range; rows past M / N are
     // never stored) so the compiler can leave them in flight across the MFMA block -- a per-load bounds branch
     // makes hipcc drain vmcnt(0) right after issuing them.  Only the last, partial K-tile takes the guarded form.
@@ -256,14 +262,12 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             const int iy = coy[i] + ky - 1, ix = cox[i] + kx - 1;
             const bool ok = kok && crow_ok[i] && iy >= 0 && iy < g.conv_h && ix >= 0 && ix < g.conv_w;
             const int64_t off = ok ? (((int64_t)cn[i] * g.conv_h + iy) * g.conv_w + ix) * g.conv_cin + ci : 0;
-            const float4 v = *reinterpret_cast<const float4 *>(g.A + off);
-            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[i] = *reinterpret_cast<const float4 *>(g.A + off);
+            za[i] = !ok;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 wv = *reinterpret_cast<const float4 *>(wrow[i] - kk + kc);     // row clamped, k clamped
-            rw[i] = kok ? wv : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < 4; ++i) rw[i] = *reinterpret_cast<const float4 *>(wrow[i] - kk + kc);     // row clamped, k clamped
+        zw = !kok;
     };
     // ---- segmented-K loader (LSTM step): tiles [0, nk1) walk [A | W] over K, tiles [nk1, nk1+nk2) walk [A2 | W2]
     // over K2; a partial tile is zero-selected after an unconditional clamped load (fma(0,0,acc) == acc).
@@ -277,25 +281,33 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const float *ap = (second ? arow2[i] : arow[i]) - kk + kc;
-            const float4 av = *reinterpret_cast<const float4 *>(ap);
-            ra[i] = kok ? av : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[i] = *reinterpret_cast<const float4 *>(ap);
+            za[i] = !kok;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float *wp = (second ? wrow2[i] : wrow[i]) - kk + kc;
-            const float4 wv = *reinterpret_cast<const float4 *>(wp);
-            rw[i] = kok ? wv : make_float4(0.f, 0.f, 0.f, 0.f);
+            rw[i] = *reinterpret_cast<const float4 *>(wp);
         }
+        zw = !kok;
     };
     const int nk_full = LSTM ? nk1 + (g.K2 + MBK - 1) / MBK
                              : CONV ? (g.K + MBK - 1) / MBK : g.K / MBK;     // conv / lstm: every tile through a select loader
     auto swrite = [&](int b) {
         float *As = lds + b * (TBM + MBN) * MLD, *Ws = As + TBM * MLD;
 #pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
+            float4 v = ra[i];
+            if (CONV || LSTM) { const bool z = za[i]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
+            *reinterpret_cast<float4 *>(&As[row * MLD + kk]) = v;
+        }
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
-            if (i < NA) *reinterpret_cast<float4 *>(&As[row * MLD + kk]) = ra[i];
-            *reinterpret_cast<float4 *>(&Ws[row * MLD + kk]) = rw[i];
+            float4 v = rw[i];
+            if (CONV || LSTM) { v.x = zw ? 0.f : v.x; v.y = zw ? 0.f : v.y; v.z = zw ? 0.f : v.z; v.w = zw ? 0.f : v.w; }
+            *reinterpret_cast<float4 *>(&Ws[row * MLD + kk]) = v;
         }
     };
     auto compute = [&](int b) {
