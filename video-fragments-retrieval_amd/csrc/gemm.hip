@@ -133,7 +133,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
     int64_t m0 = (int64_t)blockIdx.x * TBM;
     int n0 = blockIdx.y * MBN;
-    if (!CONV && !LSTM && g.xcd_cols > 0) {
+    if (!LSTM && g.xcd_cols > 0) {
         const unsigned L = blockIdx.x, per = 8u * (unsigned)g.xcd_cols, within = L % per;
         m0 = ((int64_t)(L / per) * 8 + (within & 7u)) * TBM;
         n0 = (int)(within >> 3) * MBN;
@@ -614,7 +614,13 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
         VFR_REQUIRE((g.conv_cin & 3) == 0 && g.K == 9 * g.conv_cin && (g.ldw & 3) == 0 &&
                         ((((uintptr_t)g.A) | ((uintptr_t)g.W)) & 15) == 0,
                     VFR_EINVAL, "gemm_nt(conv): needs Cin %% 4 == 0, K = 9*Cin and 16-byte aligned operands");
-        hipLaunchKernelGGL(conv3x3_nhwc_mfma, grid, dim3(256), 0, st, g);
+        if (grid.y > 1 && grid.y <= 16 && grid.x >= 64) {     // XCD-aware tile order (see xcd_cols): activations stream once
+            GemmArgs gx = g;
+            gx.xcd_cols = (int)grid.y;
+            hipLaunchKernelGGL(conv3x3_nhwc_mfma, dim3((unsigned)(cdiv(grid.x, 8) * 8 * grid.y)), dim3(256), 0, st, gx);
+        } else {
+            hipLaunchKernelGGL(conv3x3_nhwc_mfma, grid, dim3(256), 0, st, g);
+        }
         VFR_CHECK_LAUNCH("conv3x3_nhwc_mfma");
         return VFR_OK;
     }
