@@ -88,6 +88,12 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
 // fp32 MFMA runs at the fp32 vector rate (64 cycles per 32x32x2 per SIMD): this kernel is MFMA-pipe-bound,
 // staging has ~4096 cycles of cover per K-tile.
 // ------------------------------------------------------------------------------------------------
+#ifndef VFR_LSTM_NBUF
+#define VFR_LSTM_NBUF 2      // the fused LSTM step's own choice (experiment switch)
+#endif
+#ifndef VFR_LSTM_WAVES
+#define VFR_LSTM_WAVES 2
+#endif
 #ifndef VFR_GEMM_NBUF
 #define VFR_GEMM_NBUF 2      // LDS tile buffers: 2 = double buffered (2 workgroups/CU), 1 = single (3 workgroups/CU)
 #endif
@@ -128,7 +134,8 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
     constexpr int TBM = 64 * MI, NA = 2 * MI;           // tile rows; float4 staging loads of A per thread (W: 4)
     // double-buffered tiles: [2][A TBMx36 | W 128x36] floats (73,728 B at MI = 2) -> two workgroups per CU
-    __shared__ __attribute__((aligned(16))) float lds[VFR_GEMM_NBUF * (TBM + MBN) * MLD];
+    constexpr int NBUF = LSTM ? VFR_LSTM_NBUF : VFR_GEMM_NBUF;
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * (TBM + MBN) * MLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
     int64_t m0 = (int64_t)blockIdx.x * TBM;
@@ -366,22 +373,22 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         gload_main(nxt * MBK);
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
         if (VFR_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(1);
-        compute(kt % VFR_GEMM_NBUF);
+        compute(kt % NBUF);
         if (VFR_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // the other buffer was last read in iteration kt-1 and every wave has passed that iteration's barrier:
         // refill it now (overlapping the other waves' MFMAs); one barrier per K-tile
-        if (VFR_GEMM_NBUF == 1) __syncthreads();     // single buffer: everyone must finish reading before the refill
-        swrite((kt + 1) % VFR_GEMM_NBUF);
+        if (NBUF == 1) __syncthreads();     // single buffer: everyone must finish reading before the refill
+        swrite((kt + 1) % NBUF);
 #ifndef VFR_GEMM_NOSYNC
         __syncthreads();
 #endif
     }
     if (!CONV && !LSTM && (g.K % MBK)) {   // partial last tile: guarded loads, zero padded (fma(0,0,acc) == acc)
         gload_tail(nk_full * MBK);
-        swrite(nk_full % VFR_GEMM_NBUF);
+        swrite(nk_full % NBUF);
         __syncthreads();
-        compute(nk_full % VFR_GEMM_NBUF);
+        compute(nk_full % NBUF);
     }
 
     GSTAMP(1)
@@ -499,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp) { gemm_
 __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true>(g); }
 
 template <int MI>
-__global__ __launch_bounds__(256, 2) void lstm_step_mfma_pair(GemmPair gp) { gemm_nt_mfma_body<true, false, true, MI>(gp.p[blockIdx.z]); }
+__global__ __launch_bounds__(256, VFR_LSTM_WAVES) void lstm_step_mfma_pair(GemmPair gp) { gemm_nt_mfma_body<true, false, true, MI>(gp.p[blockIdx.z]); }
 
 __global__ __launch_bounds__(256) void repack_rows_kernel(const float *__restrict__ src, int64_t ld_src, int rows, int cols,
                                                           float *__restrict__ dst)
