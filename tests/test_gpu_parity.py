@@ -425,3 +425,25 @@ def test_bilstm_tile_shapes_agree(vfr, oracle):
     assert torch.equal(outs[1], outs[2])
     want = oracle.bilstm_final(tokens[:64], sd["word_embedding.weight"], lstm_of(sd), sd["lang_fc.weight"], sd["lang_fc.bias"])
     assert same(outs[2][:64], want)
+
+
+@pytest.mark.gpu
+def test_gemm_ping_pong_variant_is_bit_identical(vfr):
+    """The experimental ping-pong schedule (two tile groups per 512-thread workgroup) walks k in the same order."""
+    rs = np.random.RandomState(3)
+    A, W, b = (dev(rs.randn(4100, 512).astype(np.float32)), dev(rs.randn(2050, 512).astype(np.float32)),
+               dev(rs.randn(2050).astype(np.float32)))
+    sd = synth.model_weights(4096, seed=7)
+    tokens = synth.query_tokens(1500, seed=7)
+    args = (dev(tokens), dev(sd["word_embedding.weight"]), {k: dev(v) for k, v in lstm_of(sd).items()},
+            dev(sd["lang_fc.weight"]), dev(sd["lang_fc.bias"]))
+    out = {}
+    try:
+        for pp in (0, 1):
+            vfr.set_option("gemm_pp", pp)
+            vfr.set_option("lstm_tile", 2)
+            out[pp] = (vfr.linear(A, W, b, relu=True), vfr.bilstm_final(*args))
+    finally:
+        vfr.set_option("gemm_pp", 0)
+        vfr.set_option("lstm_tile", 0)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])

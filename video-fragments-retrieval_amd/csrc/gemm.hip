@@ -129,27 +129,43 @@ __device__ unsigned long long g_gemm_stamps[4];
 
 // MI = 32-row MFMA tiles per wave along M: 2 -> 128-row workgroup tile, 1 -> 64-row tile (half the work per workgroup, for
 // launches whose 128-row grid would leave most of the chip idle or waiting on a second, nearly empty round)
-template <bool VEC, bool CONV, bool LSTM = false, int MI = 2>
+//
+// PP = ping-pong schedule (EXPERIMENT, off by default: vfr_set_option("gemm_pp", 1)).  A 512-thread workgroup holds two
+// independent 4-wave tile groups (one wave of each on every SIMD) whose phases are interleaved by workgroup barriers -- group
+// 0 runs the MFMA block of K-tile k while group 1 writes its K-tile k+1 to LDS and issues the loads of k+2, then they swap --
+// so every SIMD always has exactly one MFMA stream and a group needs a single LDS buffer.  The idea: two free-running
+// workgroups per CU pull each other into lock step (the one behind gets the whole matrix pipe while the other loads) and the
+// pipe then idles through both load blocks (PMC: 77 % occupancy dense, 59 % LSTM step).  Measured: bit-identical results but
+// SLOWER (dense 122 -> 98 TF, LSTM step 0.66 -> 0.79 ms): in-kernel stamps put 38 % of a wave's time in its MFMA blocks, 27 %
+// in its (tiny) load blocks and 25 % at the barriers -- the load block of one group crawls beside the other group's MFMA
+// block.  Kept as a switchable variant for the next round's work on that stall.
+template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false>
 __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
     constexpr int TBM = 64 * MI, NA = 2 * MI;           // tile rows; float4 staging loads of A per thread (W: 4)
     // double-buffered tiles: [2][A TBMx36 | W 128x36] floats (73,728 B at MI = 2) -> two workgroups per CU
-    constexpr int NBUF = LSTM ? VFR_LSTM_NBUF : VFR_GEMM_NBUF;
-    __shared__ __attribute__((aligned(16))) float lds[NBUF * (TBM + MBN) * MLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NBUF = PP ? 1 : (LSTM ? VFR_LSTM_NBUF : VFR_GEMM_NBUF);
+    __shared__ __attribute__((aligned(16))) float lds_all[(PP ? 2 : 1) * NBUF * (TBM + MBN) * MLD];
+    const int grp = PP ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // tile group of this wave
+    float *lds = lds_all + grp * NBUF * (TBM + MBN) * MLD;
+    const int tid = PP ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
-    int64_t m0 = (int64_t)blockIdx.x * TBM;
+    int64_t m0 = (int64_t)(PP ? blockIdx.x * 2 + grp : blockIdx.x) * TBM;
     int n0 = blockIdx.y * MBN;
+    bool active = true;                                  // PP: a group without a tile still takes part in the barriers
     if (!LSTM && g.xcd_cols > 0) {
         const unsigned L = blockIdx.x, per = 8u * (unsigned)g.xcd_cols, within = L % per;
-        m0 = ((int64_t)(L / per) * 8 + (within & 7u)) * TBM;
+        const int64_t rt = (int64_t)(L / per) * 8 + (within & 7u);
+        m0 = (PP ? rt * 2 + grp : rt) * TBM;
         n0 = (int)(within >> 3) * MBN;
-        if (m0 >= g.M) return;                           // grid padded to whole groups of 8 row tiles
+        if (m0 >= g.M) { if (!PP) return; active = false; }     // grid padded to whole groups of 8 row tiles
     }
+    if (PP && !LSTM && m0 >= g.M) active = false;
     // LSTM step with a shrinking / growing active prefix: rows past the active count do nothing this step
     const int64_t Mrows = (LSTM && g.lstm_mcount) ? (int64_t)g.lstm_mcount[g.lstm_step] : g.M;
     const int64_t Mprev = (LSTM && g.lstm_mcount) ? (g.lstm_step > 0 ? (int64_t)g.lstm_mcount[g.lstm_step - 1] : 1) : Mrows;
-    if (LSTM && m0 >= Mrows) return;
+    if (LSTM && m0 >= Mrows) { if (!PP) return; active = false; }
+    if (!active) m0 = 0;                                 // keeps every clamped address below in range; nothing is stored
 
 #ifdef VFR_GEMM_STAMPS
     unsigned long long gst[4] = {0, 0, 0, 0}, gt0 = __builtin_amdgcn_s_memtime();
@@ -321,21 +337,26 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         const float *As = lds + b * (TBM + MBN) * MLD, *Ws = As + TBM * MLD;
         const float *ap = &As[(wm * (32 * MI) + l31) * MLD];
         const float *wp = &Ws[(wn * 64 + l31) * MLD];
-        // fragment double buffer: the four ds_read_b128 of slice k4+1 are issued (and pinned) BEFORE the eight MFMAs
-        // of slice k4, so their latency hides under the matrix pipe instead of sitting between MFMA groups
-        float4 fa[2][MI], fb[2][2];
+        // fragment ring: the ds_read_b128 of slice k4+DEPTH are issued (and pinned) BEFORE the MFMAs of slice k4, so their
+        // latency hides under the matrix pipe.  DEPTH 1 is enough when two workgroups interleave on the SIMD; the ping-pong
+        // schedule has a single MFMA stream per SIMD and needs two slices (1024 pipe cycles) of cover.
+        constexpr int DEPTH = PP ? 2 : 1, RING = DEPTH + 1;
+        float4 fa[RING][MI], fb[RING][2];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) fa[0][mi] = *reinterpret_cast<const float4 *>(ap + mi * 32 * MLD);
-        fb[0][0] = *reinterpret_cast<const float4 *>(wp);
-        fb[0][1] = *reinterpret_cast<const float4 *>(wp + 32 * MLD);
+        for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) fa[d][mi] = *reinterpret_cast<const float4 *>(ap + mi * 32 * MLD + d * 4);
+            fb[d][0] = *reinterpret_cast<const float4 *>(wp + d * 4);
+            fb[d][1] = *reinterpret_cast<const float4 *>(wp + 32 * MLD + d * 4);
+        }
 #pragma unroll
         for (int k4 = 0; k4 < MBK / 4; ++k4) {
-            const int cur = k4 & 1, nxt = cur ^ 1;
-            if (k4 + 1 < MBK / 4) {
+            const int cur = k4 % RING, nxt = (k4 + DEPTH) % RING;
+            if (k4 + DEPTH < MBK / 4) {
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) fa[nxt][mi] = *reinterpret_cast<const float4 *>(ap + mi * 32 * MLD + (k4 + 1) * 4);
-                fb[nxt][0] = *reinterpret_cast<const float4 *>(wp + (k4 + 1) * 4);
-                fb[nxt][1] = *reinterpret_cast<const float4 *>(wp + 32 * MLD + (k4 + 1) * 4);
+                for (int mi = 0; mi < MI; ++mi) fa[nxt][mi] = *reinterpret_cast<const float4 *>(ap + mi * 32 * MLD + (k4 + DEPTH) * 4);
+                fb[nxt][0] = *reinterpret_cast<const float4 *>(wp + (k4 + DEPTH) * 4);
+                fb[nxt][1] = *reinterpret_cast<const float4 *>(wp + 32 * MLD + (k4 + DEPTH) * 4);
             }
             __builtin_amdgcn_sched_barrier(0);
             const float4 b0 = fb[cur][0], b1 = fb[cur][1];
@@ -365,6 +386,23 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // iteration re-reads its own tile, which is harmless) so no control-flow join sits between the loads and the
     // MFMA block -- a join there makes the compiler drain vmcnt(0) before the first MFMA.
     auto gload_main = [&](int k0) { if (LSTM) gload_seg(k0); else if (CONV) gload_conv(k0); else gload_full(k0); };
+    if (PP) {
+        // group g runs  C0 L1 C1 L2 ... C(nk-1)  delayed by g phases;  Ck = MFMA block on K-tile k (LDS), Lk = K-tile k from
+        // registers to LDS + issue the loads of K-tile k+1.  One workgroup barrier per phase.
+        const int nk = nk_full;
+        if (active && nk > 0) { gload_main(0); swrite(0); if (nk > 1) gload_main(MBK); }
+        __syncthreads();
+        GSTAMP(0)
+        for (int p = 0; p < 2 * nk; ++p) {
+            const int q = p - grp;
+            if (active && q >= 0 && q < 2 * nk - 1) {
+                const int k = q >> 1;
+                if (q & 1) { swrite(0); if (k + 2 < nk) gload_main((k + 2) * MBK); }
+                else compute(0);
+            }
+            __syncthreads();
+        }
+    } else {
     if (nk_full > 0) { gload_main(0); swrite(0); }
     __syncthreads();
     GSTAMP(0)
@@ -390,6 +428,8 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         __syncthreads();
         compute(nk_full % NBUF);
     }
+    }
+    if (PP && !active) return;
 
     GSTAMP(1)
     if (LSTM) {
@@ -507,6 +547,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_n
 
 template <int MI>
 __global__ __launch_bounds__(256, VFR_LSTM_WAVES) void lstm_step_mfma_pair(GemmPair gp) { gemm_nt_mfma_body<true, false, true, MI>(gp.p[blockIdx.z]); }
+__global__ __launch_bounds__(512, 2) void lstm_step_mfma_pair_pp(GemmPair gp) { gemm_nt_mfma_body<true, false, true, 2, true>(gp.p[blockIdx.z]); }
+template <bool VEC>
+__global__ __launch_bounds__(512, 2) void gemm_nt_mfma_pp(GemmArgs g) { gemm_nt_mfma_body<VEC, false, false, 2, true>(g); }
 
 __global__ __launch_bounds__(256) void repack_rows_kernel(const float *__restrict__ src, int64_t ld_src, int rows, int cols,
                                                           float *__restrict__ dst)
@@ -574,6 +617,9 @@ int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
     if (opt_lstm_tile() == 1 || (opt_lstm_tile() == 0 && wgs128 < 768)) {
         dim3 grid((unsigned)cdiv(g0.M, 64), (unsigned)cdiv(g0.lstm_H, 32), 2);
         hipLaunchKernelGGL(lstm_step_mfma_pair<1>, grid, dim3(256), 0, st, gp);
+    } else if (opt_gemm_pp()) {
+        dim3 grid((unsigned)cdiv(cdiv(g0.M, MBM), 2), (unsigned)cdiv(g0.lstm_H, 32), 2);
+        hipLaunchKernelGGL(lstm_step_mfma_pair_pp, grid, dim3(512), 0, st, gp);
     } else {
         dim3 grid((unsigned)cdiv(g0.M, MBM), (unsigned)cdiv(g0.lstm_H, 32), 2);
         hipLaunchKernelGGL(lstm_step_mfma_pair<2>, grid, dim3(256), 0, st, gp);
@@ -646,14 +692,28 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
         VFR_CHECK_LAUNCH("gemm_nt_mfma<64>");
         return VFR_OK;
     }
+    const bool pp = opt_gemm_pp() && (g.K % MBK) == 0 && g.K >= 2 * MBK;
     if (grid.y > 1 && grid.y <= 16 && grid.x >= 64) {
         // tall GEMM with a few column tiles (the clip encoder's seg x W1: 1641 x 4): XCD-aware tile order, see xcd_cols
         GemmArgs gx = g;
         gx.xcd_cols = (int)grid.y;
-        dim3 grid1((unsigned)(cdiv(grid.x, 8) * 8 * grid.y));
-        if (vec) hipLaunchKernelGGL(gemm_nt_mfma<true>, grid1, dim3(256), 0, st, gx);
-        else     hipLaunchKernelGGL(gemm_nt_mfma<false>, grid1, dim3(256), 0, st, gx);
+        if (pp) {
+            dim3 grid1((unsigned)(cdiv(cdiv(grid.x, 2), 8) * 8 * grid.y));
+            if (vec) hipLaunchKernelGGL(gemm_nt_mfma_pp<true>, grid1, dim3(512), 0, st, gx);
+            else     hipLaunchKernelGGL(gemm_nt_mfma_pp<false>, grid1, dim3(512), 0, st, gx);
+        } else {
+            dim3 grid1((unsigned)(cdiv(grid.x, 8) * 8 * grid.y));
+            if (vec) hipLaunchKernelGGL(gemm_nt_mfma<true>, grid1, dim3(256), 0, st, gx);
+            else     hipLaunchKernelGGL(gemm_nt_mfma<false>, grid1, dim3(256), 0, st, gx);
+        }
         VFR_CHECK_LAUNCH("gemm_nt_mfma(xcd)");
+        return VFR_OK;
+    }
+    if (pp) {
+        dim3 grid2((unsigned)cdiv(grid.x, 2), grid.y);
+        if (vec) hipLaunchKernelGGL(gemm_nt_mfma_pp<true>, grid2, dim3(512), 0, st, g);
+        else     hipLaunchKernelGGL(gemm_nt_mfma_pp<false>, grid2, dim3(512), 0, st, g);
+        VFR_CHECK_LAUNCH("gemm_nt_mfma_pp");
         return VFR_OK;
     }
     if (vec) hipLaunchKernelGGL(gemm_nt_mfma<true>, grid, dim3(256), 0, st, g);

@@ -20,6 +20,7 @@ int opt_gemm();
 int opt_score_fast();
 int opt_score_split();
 int opt_lstm_tile();
+int opt_gemm_pp();
 
 // ---- launch-site profiler (vfr_set_option("profile", 1)): HIP events recorded on the launch stream
 // around every instrumented launch; vfr_profile_read() turns them into per-site totals after a sync.
