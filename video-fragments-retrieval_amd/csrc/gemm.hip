@@ -138,7 +138,8 @@ __device__ unsigned long long g_gemm_stamps[4];
 // pipe then idles through both load blocks (PMC: 77 % occupancy dense, 59 % LSTM step).  Measured: bit-identical results but
 // SLOWER (dense 122 -> 98 TF, LSTM step 0.66 -> 0.79 ms): in-kernel stamps put 38 % of a wave's time in its MFMA blocks, 27 %
 // in its (tiny) load blocks and 25 % at the barriers -- the load block of one group crawls beside the other group's MFMA
-// block.  Kept as a switchable variant for the next round's work on that stall.
+// block (raising that block's wave priority with s_setprio changes nothing).  Kept as a switchable variant for the next round's
+// work on that stall.
 template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false>
 __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
