@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
 #define VFR_GEMM_SETPRIO 0
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int MBM = 128, MBN = 128, MBK = 32, MLD = 36;
 
 template <bool VEC>
@@ -150,7 +151,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     const int grp = PP ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // tile group of this wave
     float *lds = lds_all + grp * NBUF * (TBM + MBN) * MLD;
     const int tid = PP ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
     int64_t m0 = (int64_t)(PP ? blockIdx.x * 2 + grp : blockIdx.x) * TBM;
     int n0 = blockIdx.y * MBN;
     bool active = true;                                  // PP: a group without a tile still takes part in the barriers
@@ -171,37 +172,40 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #ifdef VFR_GEMM_STAMPS
     unsigned long long gst[4] = {0, 0, 0, 0}, gt0 = __builtin_amdgcn_s_memtime();
 #endif
-    f32x16 acc[MI][2];
+    // accumulators: the wave's 16*TI x 64 outputs as TI x 4 tiles of v_mfma_f32_16x16x4_f32 (4 registers each); lane l holds
+    // rows 4*(l>>4) + r (r = 0..3) and column l & 15 of a tile
+    constexpr int TI = 2 * MI;
+    const int l15 = lane & 15, lq = lane >> 4;
+    f32x4 acc[TI][4];
     if (LSTM && g.lstm_tok) {
         // chains start from the vocabulary input-projection table: P[lstm_tok[row]][tile column].  Two batched load
-        // rounds (all 32 table-row indices, then all 64 accumulators), not 32 dependent pairs one after the other.
-        int64_t prow[MI][16];
+        // rounds (all table-row indices, then all accumulators), not dependent pairs one after the other.
+        int64_t prow[TI][4];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                prow[mi][r] = (int64_t)g.lstm_tok[row < Mrows ? row : Mrows - 1];
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq + r;
+                prow[ti][r] = (int64_t)g.lstm_tok[row < Mrows ? row : Mrows - 1];
             }
-        const float *pcol = g.Cin + (int64_t)blockIdx.y * MBN + wn * 64 + l31;
+        const float *pcol = g.Cin + (int64_t)blockIdx.y * MBN + wn * 64 + l15;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[mi][0][r] = pcol[prow[mi][r] * g.ldc];
-                acc[mi][1][r] = pcol[prow[mi][r] * g.ldc + 32];
-            }
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) acc[ti][tj][r] = pcol[prow[ti][r] * g.ldc + tj * 16];
     } else {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+        for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+            for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int col = n0 + wn * 64 + ni * 32 + l31;
-                acc[mi][ni][r] = (g.Cin && row < g.M && col < g.N) ? g.Cin[row * g.ldc + col] : 0.0f;
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq + r;
+                    const int col = n0 + wn * 64 + tj * 16 + l15;
+                    acc[ti][tj][r] = (g.Cin && row < g.M && col < g.N) ? g.Cin[row * g.ldc + col] : 0.0f;
+                }
     }
 
     float4 ra[NA], rw[4];
@@ -219,8 +223,8 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     for (int i = 0; i < 4; ++i) {
         const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
         int64_t nw = (int64_t)n0 + row < g.N ? (int64_t)n0 + row : g.N - 1;
-        if (LSTM) {   // tile row R = (wn, ni, l31): gate = 2*ni + (l31 >> 4), unit = 32*blockIdx.y + 16*wn + (l31 & 15)
-            const int gate = ((row >> 5) & 1) * 2 + ((row >> 4) & 1);
+        if (LSTM) {   // tile column c = (wn, tj, l15): gate = tj = (c >> 4) & 3, unit = 32*blockIdx.y + 16*wn + (c & 15)
+            const int gate = (row >> 4) & 3;
             int unit = blockIdx.y * 32 + (row >> 6) * 16 + (row & 15);
             unit = unit < g.lstm_H ? unit : g.lstm_H - 1;
             nw = (int64_t)gate * g.lstm_H + unit;
@@ -336,49 +340,37 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     };
     auto compute = [&](int b) {
         const float *As = lds + b * (TBM + MBN) * MLD, *Ws = As + TBM * MLD;
-        const float *ap = &As[(wm * (32 * MI) + l31) * MLD];
-        const float *wp = &Ws[(wn * 64 + l31) * MLD];
-        // fragment ring: the ds_read_b128 of slice k4+DEPTH are issued (and pinned) BEFORE the MFMAs of slice k4, so their
-        // latency hides under the matrix pipe.  DEPTH 1 is enough when two workgroups interleave on the SIMD; the ping-pong
-        // schedule has a single MFMA stream per SIMD and needs two slices (1024 pipe cycles) of cover.
+        // fragment of tile row block ti at k-slice k4: ONE dword per lane, A[16*ti + (lane & 15)][4*k4 + (lane >> 4)] -- exactly
+        // the 16x16x4 operand layout, read with ds_read_b32 (bank = 36*r + q mod 64: 64 distinct banks, conflict-free)
+        const float *ap = &As[(wm * (16 * TI) + l15) * MLD + lq];
+        const float *wp = &Ws[(wn * 64 + l15) * MLD + lq];
+        // fragment ring: the reads of slice k4+DEPTH are issued (and pinned) BEFORE the MFMAs of slice k4, so their
+        // latency hides under the matrix pipe
         constexpr int DEPTH = PP ? 2 : 1, RING = DEPTH + 1;
-        float4 fa[RING][MI], fb[RING][2];
+        float fa[RING][TI], fb[RING][4];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) fa[d][mi] = *reinterpret_cast<const float4 *>(ap + mi * 32 * MLD + d * 4);
-            fb[d][0] = *reinterpret_cast<const float4 *>(wp + d * 4);
-            fb[d][1] = *reinterpret_cast<const float4 *>(wp + 32 * MLD + d * 4);
+            for (int ti = 0; ti < TI; ++ti) fa[d][ti] = ap[ti * 16 * MLD + d * 4];
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) fb[d][tj] = wp[tj * 16 * MLD + d * 4];
         }
 #pragma unroll
         for (int k4 = 0; k4 < MBK / 4; ++k4) {
             const int cur = k4 % RING, nxt = (k4 + DEPTH) % RING;
             if (k4 + DEPTH < MBK / 4) {
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) fa[nxt][mi] = *reinterpret_cast<const float4 *>(ap + mi * 32 * MLD + (k4 + DEPTH) * 4);
-                fb[nxt][0] = *reinterpret_cast<const float4 *>(wp + (k4 + DEPTH) * 4);
-                fb[nxt][1] = *reinterpret_cast<const float4 *>(wp + 32 * MLD + (k4 + DEPTH) * 4);
+                for (int ti = 0; ti < TI; ++ti) fa[nxt][ti] = ap[ti * 16 * MLD + (k4 + DEPTH) * 4];
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) fb[nxt][tj] = wp[tj * 16 * MLD + (k4 + DEPTH) * 4];
             }
             __builtin_amdgcn_sched_barrier(0);
-            const float4 b0 = fb[cur][0], b1 = fb[cur][1];
-            {   // k = 4*k4 + h
-                const float fb0 = h ? b0.y : b0.x, fb1 = h ? b1.y : b1.x;
+            // one MFMA = k, k+1, k+2, k+3 in order on top of the accumulator: the oracle's chain
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const float fam = h ? fa[cur][mi].y : fa[cur][mi].x;
-                    acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fam, fb0, acc[mi][0], 0, 0, 0);
-                    acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fam, fb1, acc[mi][1], 0, 0, 0);
-                }
-            }
-            {   // k = 4*k4 + 2 + h
-                const float fb0 = h ? b0.w : b0.z, fb1 = h ? b1.w : b1.z;
+            for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const float fam = h ? fa[cur][mi].w : fa[cur][mi].z;
-                    acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fam, fb0, acc[mi][0], 0, 0, 0);
-                    acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fam, fb1, acc[mi][1], 0, 0, 0);
-                }
-            }
+                for (int tj = 0; tj < 4; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][ti], fb[cur][tj], acc[ti][tj], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -434,61 +426,47 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 
     GSTAMP(1)
     if (LSTM) {
-        // lane l31 < 16 holds gates (i | g) of unit u in tiles ni = 0 | 1, lane l31 + 16 holds (f | o) of the same unit.
-        // The pair swaps what the other needs and splits the rows: the low lane finishes even r, the high lane odd r.
-        const int H = g.lstm_H, unit = blockIdx.y * 32 + wn * 16 + (l31 & 15);
-        const bool hi_lane = l31 >= 16, valid = unit < H;
+        // tile columns are (gate, unit): a lane holds i, f, g, o of unit 32*blockIdx.y + 16*wn + (lane & 15) in its four column
+        // tiles, for 4*TI rows -- every cell is finished by ONE lane, no exchange
+        const int H = g.lstm_H, unit = blockIdx.y * 32 + wn * 16 + l15;
+        const bool valid = unit < H;
         const int uc = valid ? unit : H - 1;
         const float bi = g.bias[uc] + g.bias2[uc], bf = g.bias[H + uc] + g.bias2[H + uc];
         const float bg = g.bias[2 * H + uc] + g.bias2[2 * H + uc], bo = g.bias[3 * H + uc] + g.bias2[3 * H + uc];
-        // item (mi, j): row r = 2j + hi_lane.  Everything is branch-free and batched: 16 previous-cell loads up front (clamped
-        // addresses), 32 exchanges (each lane sends only the half its partner finishes), 16 independent gate evaluations the
-        // scheduler can interleave, predicated stores last.
-        float cprev[MI][8], xi[MI][8], xf[MI][8], xg[MI][8], xo[MI][8];
-        int64_t orow[MI][8];
+        // batched and branch-free: the previous-cell loads first (clamped addresses), then 4*TI independent gate evaluations
+        // in ONE basic block (the asm pins the results ahead of the predicated stores; hipcc otherwise sinks each cell's ~190
+        // instructions into its own store predicate, one serial dependency chain after the other)
+        float cprev[TI][4], cnew[TI][4], hnew[TI][4];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int r0 = 2 * j, r1 = 2 * j + 1;
-                const int64_t rowe = m0 + wm * (32 * MI) + mi * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * h;     // r1's row = rowe + 1
-                const int64_t row = rowe + (hi_lane ? 1 : 0);
-                orow[mi][j] = row;
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq + r;
                 const int64_t rc = row < Mrows ? row : Mrows - 1;
-                cprev[mi][j] = g.lstm_cin[(rc >= Mprev ? 0 : rc) * H + uc];
-                // (the four accumulators go through an empty asm first: otherwise LLVM folds "c ? v[r1] : v[r0]" into a
-                // DYNAMIC vector index v[c ? r1 : r0], which it then lowers to a 16-way compare/select chain per extract)
-                float e00 = acc[mi][0][r0], e01 = acc[mi][0][r1], e10 = acc[mi][1][r0], e11 = acc[mi][1][r1];
-                asm volatile("" : "+v"(e00), "+v"(e01), "+v"(e10), "+v"(e11));
-                const float own0 = hi_lane ? e01 : e00, own1 = hi_lane ? e11 : e10;
-                const float snd0 = hi_lane ? e00 : e01, snd1 = hi_lane ? e10 : e11;
-                const float p0 = __shfl_xor(snd0, 16, 64), p1 = __shfl_xor(snd1, 16, 64);
-                xi[mi][j] = hi_lane ? p0 : own0; xf[mi][j] = hi_lane ? own0 : p0;
-                xg[mi][j] = hi_lane ? p1 : own1; xo[mi][j] = hi_lane ? own1 : p1;
-            }
-        // all cells in ONE basic block (the asm pins the results ahead of the predicated stores; hipcc otherwise sinks each
-        // cell's ~190 instructions into its own store predicate, one serial dependency chain after the other)
-        float cnew[MI][8], hnew[MI][8];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float ig = c_sigmoidf(xi[mi][j] + bi);
-                const float fg = c_sigmoidf(xf[mi][j] + bf);
-                const float gg = c_tanhf(xg[mi][j] + bg);
-                const float og = c_sigmoidf(xo[mi][j] + bo);
-                cnew[mi][j] = __builtin_fmaf(fg, cprev[mi][j], ig * gg);
-                hnew[mi][j] = og * c_tanhf(cnew[mi][j]);
-                asm volatile("" : "+v"(cnew[mi][j]), "+v"(hnew[mi][j]));
+                cprev[ti][r] = g.lstm_cin[(rc >= Mprev ? 0 : rc) * H + uc];
             }
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (valid && orow[mi][j] < Mrows) {
-                    g.lstm_c[orow[mi][j] * H + unit] = cnew[mi][j];
-                    g.lstm_h[orow[mi][j] * g.lstm_ldh + unit] = hnew[mi][j];
+            for (int r = 0; r < 4; ++r) {
+                const float ig = c_sigmoidf(acc[ti][0][r] + bi);
+                const float fg = c_sigmoidf(acc[ti][1][r] + bf);
+                const float gg = c_tanhf(acc[ti][2][r] + bg);
+                const float og = c_sigmoidf(acc[ti][3][r] + bo);
+                cnew[ti][r] = __builtin_fmaf(fg, cprev[ti][r], ig * gg);
+                hnew[ti][r] = og * c_tanhf(cnew[ti][r]);
+                asm volatile("" : "+v"(cnew[ti][r]), "+v"(hnew[ti][r]));
+            }
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq + r;
+                if (valid && row < Mrows) {
+                    g.lstm_c[row * H + unit] = cnew[ti][r];
+                    g.lstm_h[row * g.lstm_ldh + unit] = hnew[ti][r];
                 }
+            }
         GSTAMP(2)
 #ifdef VFR_GEMM_STAMPS
         if (lane == 0) for (int i = 0; i < 3; ++i) atomicAdd(&g_gemm_stamps[i], gst[i]);
@@ -497,10 +475,10 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         return;
     }
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = n0 + wn * 64 + ni * 32 + l31;
+        for (int tj = 0; tj < 4; ++tj) {
+            const int col = n0 + wn * 64 + tj * 16 + l15;
             if (col >= g.N) continue;
             float badd = 0.0f;
             if (g.epi & EPI_BIAS2) badd = g.bias[col] + g.bias2[col];
@@ -509,28 +487,28 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 // hidden layer of the clip encoder fused here: the S array never exists in HBM.  Loads first (clamped
                 // rows, no branches), then the arithmetic, then predicated stores.
                 const float w0 = g.vis_w0[col], w1 = g.vis_w1[col], b = g.bias[col];
-                float cx[16], t0[16], t1[16];
+                float cx[4], t0[4], t1[4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq + r;
                     const int64_t rc = row < g.M ? row : g.M - 1;
                     t0[r] = g.vis_te[2 * rc]; t1[r] = g.vis_te[2 * rc + 1];
                     cx[r] = g.vis_cx[(int64_t)g.vis_row[rc] * g.N + col];
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq + r;
                     const float te = __builtin_fmaf(t1[r], w1, __builtin_fmaf(t0[r], w0, 0.0f));
-                    const float x = ((acc[mi][ni][r] + cx[r]) + te) + b;
+                    const float x = ((acc[ti][tj][r] + cx[r]) + te) + b;
                     if (row < g.M) g.out[row * g.ldo + col] = x > 0.0f ? x : 0.0f;
                 }
                 continue;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq + r;
                 if (row >= g.M) continue;
-                float v = acc[mi][ni][r];
+                float v = acc[ti][tj][r];
                 if (g.epi & (EPI_BIAS | EPI_BIAS2)) v = v + badd;
                 if (g.epi & EPI_RELU) v = v > 0.0f ? v : 0.0f;
                 g.out[row * g.ldo + col] = v;
@@ -562,7 +540,7 @@ __global__ __launch_bounds__(256) void repack_rows_kernel(const float *__restric
 }
 
 // W [4H, E] -> the fused step's tile-column order [128 * ceil(H/32), E] (zero rows for units >= H): tile column
-// c = 128*tile + rr holds gate 2*((rr>>5)&1) + ((rr>>4)&1) of unit 32*tile + 16*(rr>>6) + (rr&15)
+// c = 128*tile + rr holds gate (rr>>4)&3 of unit 32*tile + 16*(rr>>6) + (rr&15)
 __global__ __launch_bounds__(256) void lstm_permute_rows_kernel(const float *__restrict__ W, int H, int E, int ncols,
                                                                 float *__restrict__ out)
 {
@@ -570,7 +548,7 @@ __global__ __launch_bounds__(256) void lstm_permute_rows_kernel(const float *__r
     if (i >= (int64_t)ncols * E) return;
     const int c = (int)(i / E), k = (int)(i - (int64_t)c * E);
     const int tile = c >> 7, rr = c & 127;
-    const int gate = ((rr >> 5) & 1) * 2 + ((rr >> 4) & 1), unit = tile * 32 + (rr >> 6) * 16 + (rr & 15);
+    const int gate = (rr >> 4) & 3, unit = tile * 32 + (rr >> 6) * 16 + (rr & 15);
     out[i] = unit < H ? W[((int64_t)gate * H + unit) * E + k] : 0.0f;
 }
 
