@@ -590,10 +590,10 @@ int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
     }
     ProfScope prof(g0.site, st);
     GemmPair gp{{g0, g1}};
-    // 64-row tiles when the 128-row grid would not even fill the chip's 512 workgroup slots 1.5 times: the step is then a
-    // tile's latency, and half-size tiles spread the same work over twice as many waves
-    const int64_t wgs128 = cdiv(g0.M, MBM) * cdiv(g0.lstm_H, 32) * 2;
-    if (opt_lstm_tile() == 1 || (opt_lstm_tile() == 0 && wgs128 < 768)) {
+    // 64-row tiles by default: a step is only a few rounds of the chip's 512 workgroup slots, a partial last round of
+    // 128-row tiles costs as much as a full one (a workgroup alone on a CU is not twice as fast), and half-size tiles halve that
+    // loss -- measured faster at every batch size from 625 to 5000 queries (lstm_tile = 2 forces 128 rows)
+    if (opt_lstm_tile() != 2) {
         dim3 grid((unsigned)cdiv(g0.M, 64), (unsigned)cdiv(g0.lstm_H, 32), 2);
         hipLaunchKernelGGL(lstm_step_mfma_pair<1>, grid, dim3(256), 0, st, gp);
     } else if (opt_gemm_pp()) {
