@@ -91,6 +91,9 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
 #ifndef VFR_LSTM_NBUF
 #define VFR_LSTM_NBUF 2      // the fused LSTM step's own choice (experiment switch)
 #endif
+#ifndef VFR_LSTM_DEPTH
+#define VFR_LSTM_DEPTH 1     // fragment prefetch distance (k-slices) of the fused LSTM step; the other MFMA kernels use 2
+#endif
 #ifndef VFR_LSTM_WAVES
 #define VFR_LSTM_WAVES 2
 #endif
@@ -345,8 +348,10 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         const float *ap = &As[(wm * (16 * TI) + l15) * MLD + lq];
         const float *wp = &Ws[(wn * 64 + l15) * MLD + lq];
         // fragment ring: the reads of slice k4+DEPTH are issued (and pinned) BEFORE the MFMAs of slice k4, so their
-        // latency hides under the matrix pipe
-        constexpr int DEPTH = PP ? 2 : 1, RING = DEPTH + 1;
+        // latency hides under the matrix pipe.  DEPTH 2 matters when a workgroup is ALONE on its CU (partial last round, small
+        // launches): with one slice of cover a lone wave's stream stalled on LDS latency and a half-filled round cost as much
+        // as a full one; with two it costs half.  The LSTM step (64-row tiles, always several rounds) is 1.5 % faster with 1.
+        constexpr int DEPTH = LSTM ? VFR_LSTM_DEPTH : 2, RING = DEPTH + 1;
         float fa[RING][TI], fb[RING][4];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
