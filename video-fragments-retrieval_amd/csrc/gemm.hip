@@ -91,6 +91,9 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
 #ifndef VFR_LSTM_NBUF
 #define VFR_LSTM_NBUF 2      // the fused LSTM step's own choice (experiment switch)
 #endif
+#ifndef VFR_GEMM_PIPE
+#define VFR_GEMM_PIPE 1      // 1: K-tile loop software-pipelined across the tile boundary (see the main loop); 0: the plain loop
+#endif
 #ifndef VFR_LSTM_DEPTH
 #define VFR_LSTM_DEPTH 1     // fragment prefetch distance (k-slices) of the fused LSTM step; the other MFMA kernels use 2
 #endif
@@ -399,6 +402,60 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 else compute(0);
             }
             __syncthreads();
+        }
+    } else if (NBUF == 2 && VFR_GEMM_PIPE) {
+        // K-tile loop, software-pipelined so that NOTHING but the barrier itself sits between two MFMA blocks.  Per K-tile kt
+        // (8 k-slices of 4, TI*4 MFMAs each):
+        //   slice 1   registers (K-tile kt+1, loaded during the previous tile) -> the other LDS buffer: it was last read for
+        //             K-tile kt-1 and every wave passed that tile's barrier after issuing its last fragment reads
+        //   slice 3   issue the global loads of K-tile kt+2 (unconditional, index clamped: no control-flow join that would
+        //             make hipcc drain vmcnt before the MFMAs)
+        //   slice 8-DEPTH  barrier (K-tile kt+1 visible), then the fragment reads continue seamlessly into K-tile kt+1
+        // so the LDS writes, the load issue and the first fragment reads of the next tile all run under MFMAs of this one.
+        constexpr int DEPTH = LSTM ? VFR_LSTM_DEPTH : 2, RING = DEPTH == 1 ? 2 : 4, NS = MBK / 4;
+        const int nk = nk_full;
+        float fa[RING][TI], fb[RING][4];
+        auto frag_read = [&](int buf, int slice, int slot) {
+            const float *As = lds + buf * (TBM + MBN) * MLD, *Ws = As + TBM * MLD;
+            const float *ap = &As[(wm * (16 * TI) + l15) * MLD + lq + slice * 4];
+            const float *wp = &Ws[(wn * 64 + l15) * MLD + lq + slice * 4];
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti) fa[slot][ti] = ap[ti * 16 * MLD];
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) fb[slot][tj] = wp[tj * 16 * MLD];
+        };
+        if (nk > 0) { gload_main(0); swrite(0); gload_main((nk > 1 ? 1 : 0) * MBK); }
+        __syncthreads();
+        GSTAMP(0)
+        if (nk > 0) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) frag_read(0, d, d % RING);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cb = kt & 1, nb = cb ^ 1;
+#pragma unroll
+            for (int k4 = 0; k4 < NS; ++k4) {
+                const int sn = k4 + DEPTH;                   // slice whose fragments are fetched now
+                if (sn == NS) __syncthreads();               // K-tile kt+1 (written at slice 1) is visible from here on
+                if (sn < NS) frag_read(cb, sn, sn % RING);
+                else         frag_read(nb, sn - NS, sn % RING);    // (past the last K-tile: stale data, never used)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 4; ++tj)
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k4 % RING][ti], fb[k4 % RING][tj], acc[ti][tj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k4 == 1) swrite(nb);
+                if (k4 == 3) { const int t2 = kt + 2 < nk ? kt + 2 : nk - 1; gload_main(t2 * MBK); }
+            }
+        }
+        if (!CONV && !LSTM && (g.K % MBK)) {   // partial last tile: guarded loads, zero padded (fma(0,0,acc) == acc)
+            __syncthreads();
+            gload_tail(nk_full * MBK);
+            swrite(0);
+            __syncthreads();
+            compute(0);
         }
     } else {
     if (nk_full > 0) { gload_main(0); swrite(0); }
