@@ -183,36 +183,38 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     constexpr int TI = 2 * MI;
     const int l15 = lane & 15, lq = lane >> 4;
     f32x4 acc[TI][4];
-    if (LSTM && g.lstm_tok) {
-        // chains start from the vocabulary input-projection table: P[lstm_tok[row]][tile column].  Two batched load
-        // rounds (all table-row indices, then all accumulators), not dependent pairs one after the other.
-        int64_t prow[TI][4];
-#pragma unroll
-        for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq + r;
-                prow[ti][r] = (int64_t)g.lstm_tok[row < Mrows ? row : Mrows - 1];
-            }
-        const float *pcol = g.Cin + (int64_t)blockIdx.y * MBN + wn * 64 + l15;
-#pragma unroll
-        for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int tj = 0; tj < 4; ++tj) acc[ti][tj][r] = pcol[prow[ti][r] * g.ldc + tj * 16];
-    } else {
-#pragma unroll
-        for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
+    auto init_acc = [&]() {
+        if (LSTM && g.lstm_tok) {
+            // chains start from the vocabulary input-projection table: P[lstm_tok[row]][tile column].  Two batched load
+            // rounds (all table-row indices, then all accumulators), not dependent pairs one after the other.
+            int64_t prow[TI][4];
+    #pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+    #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq + r;
-                    const int col = n0 + wn * 64 + tj * 16 + l15;
-                    acc[ti][tj][r] = (g.Cin && row < g.M && col < g.N) ? g.Cin[row * g.ldc + col] : 0.0f;
+                    prow[ti][r] = (int64_t)g.lstm_tok[row < Mrows ? row : Mrows - 1];
                 }
-    }
+            const float *pcol = g.Cin + (int64_t)blockIdx.y * MBN + wn * 64 + l15;
+    #pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+    #pragma unroll
+                for (int r = 0; r < 4; ++r)
+    #pragma unroll
+                    for (int tj = 0; tj < 4; ++tj) acc[ti][tj][r] = pcol[prow[ti][r] * g.ldc + tj * 16];
+        } else {
+    #pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+    #pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq + r;
+                        const int col = n0 + wn * 64 + tj * 16 + l15;
+                        acc[ti][tj][r] = (g.Cin && row < g.M && col < g.N) ? g.Cin[row * g.ldc + col] : 0.0f;
+                    }
+        }
+    };
 
     float4 ra[NA], rw[4];
     // Zero-fill of staged elements outside the operand (conv padding taps, the tail of a segmented K) is decided when the
@@ -391,6 +393,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         // group g runs  C0 L1 C1 L2 ... C(nk-1)  delayed by g phases;  Ck = MFMA block on K-tile k (LDS), Lk = K-tile k from
         // registers to LDS + issue the loads of K-tile k+1.  One workgroup barrier per phase.
         const int nk = nk_full;
+        init_acc();
         if (active && nk > 0) { gload_main(0); swrite(0); if (nk > 1) gload_main(MBK); }
         __syncthreads();
         GSTAMP(0)
@@ -424,7 +427,11 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj) fb[slot][tj] = wp[tj * 16 * MLD];
         };
-        if (nk > 0) { gload_main(0); swrite(0); gload_main((nk > 1 ? 1 : 0) * MBK); }
+        // the first K-tile's loads are in flight while the accumulators are initialised (C-in / the LSTM table gather: two
+        // dependent load rounds whose latency would otherwise stand alone at the head of every tile)
+        if (nk > 0) gload_main(0);
+        init_acc();
+        if (nk > 0) { swrite(0); gload_main((nk > 1 ? 1 : 0) * MBK); }
         __syncthreads();
         GSTAMP(0)
         if (nk > 0) {
@@ -458,6 +465,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             compute(0);
         }
     } else {
+    init_acc();
     if (nk_full > 0) { gload_main(0); swrite(0); }
     __syncthreads();
     GSTAMP(0)
