@@ -143,6 +143,21 @@ int vfr_vgg_fc7_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *
                     const float *fc6_b, const float *fc7_w, const float *fc7_b, int fc_dim, float *out,
                     void *workspace, size_t workspace_bytes, vfr_stream_t stream);
 
+/* ---- f2  training / test loss: Trainer.ranking_loss, model/main.py:214-232 (called from train_epoch :63 and
+ * test_epoch :102).  posit, inter [P,D], intra [Nn,D], lang [S,D]; maskp [P], maskn [Nn] int64 sample ids (rows whose id
+ * is outside [0,S) belong to no sample).  loss[0] = sum_i relu(c_posit - c_intra + b) + lamb*relu(c_posit - c_inter + b),
+ * c_x = mean pairwise_distance(x rows of sample i, lang[i]).  The optional normalize_loss row scaling (:219-223) is the
+ * caller's (it is plain differentiable arithmetic on the inputs).  The workspace written by the forward call (row distances,
+ * per-sample terms) is what the backward call reads; grad_loss is the upstream scalar gradient on the device.            */
+size_t vfr_ranking_loss_workspace_bytes(int64_t P, int64_t Nn, int S);
+int vfr_ranking_loss_f32(const float *posit, const float *intra, const float *inter, const float *lang, const int64_t *maskp,
+                         const int64_t *maskn, int64_t P, int64_t Nn, int S, int D, float b, float lamb, float eps,
+                         float *loss, void *workspace, size_t workspace_bytes, vfr_stream_t stream);
+int vfr_ranking_loss_grad_f32(const float *posit, const float *intra, const float *inter, const float *lang,
+                              const int64_t *maskp, const int64_t *maskn, int64_t P, int64_t Nn, int S, int D, float lamb,
+                              float eps, const float *grad_loss, const void *workspace, float *grad_posit, float *grad_intra,
+                              float *grad_inter, float *grad_lang, vfr_stream_t stream);
+
 /* ---- parity probe: elementwise canonical math (0 exp, 1 sigmoid, 2 tanh, 3 x/y, 4 sqrt,
  * 5 fma(x,y,x)) so tests can pin the device's transcendental forms against the oracle's.        */
 int vfr_math_f32(int op, const float *x, const float *y, float *out, int64_t n, vfr_stream_t stream);

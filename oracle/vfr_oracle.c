@@ -354,6 +354,43 @@ VFO_EXPORT void vfo_clip_distances(const float *Q, long Nq, const float *V, long
     for (long q = 0; q < Nq; ++q)
         for (long c = 0; c < C; ++c) dist[q * C + c] = clip_dist(V + c * D, Q + q * D, D, eps);
 }
+/* ------------------------------------------------------------------------------------------ */
+/* f2  Trainer.ranking_loss (model/main.py:214-232), the loss of train_epoch / test_epoch:       */
+/*   per sample i:  c_x = mean over the rows r of set x with mask[r] == i of                    */
+/*                        F.pairwise_distance(x[r], lang[i])   (x = posit | intra | inter)       */
+/*   loss = sum_i relu(c_posit - c_intra + b) + lamb * relu(c_posit - c_inter + b)               */
+/* canonical order: clip_dist chain per row, sequential sum in row order, IEEE divide by the     */
+/* count (0/0 = NaN like torch's mean of an empty selection), hinge terms, sequential sum over i.*/
+/* per_sample [S,8] = c_posit, c_intra, c_inter, t1, t2, n_posit, n_intra, loss_i                 */
+/* ------------------------------------------------------------------------------------------ */
+VFO_EXPORT float vfo_ranking_loss(const float *posit, const float *intra, const float *inter, const float *lang,
+                                  const int32_t *maskp, const int32_t *maskn, long P, long Nn, int S, int D, float b,
+                                  float lamb, float eps, float *per_sample)
+{
+    float loss = 0.0f;
+    for (int i = 0; i < S; ++i) {
+        float sp = 0.0f, sn = 0.0f, si = 0.0f;
+        long np_ = 0, nn_ = 0;
+        for (long r = 0; r < P; ++r)
+            if (maskp[r] == i) {
+                sp = sp + clip_dist(posit + r * D, lang + (long)i * D, D, eps);
+                si = si + clip_dist(inter + r * D, lang + (long)i * D, D, eps);
+                ++np_;
+            }
+        for (long r = 0; r < Nn; ++r)
+            if (maskn[r] == i) { sn = sn + clip_dist(intra + r * D, lang + (long)i * D, D, eps); ++nn_; }
+        const float cp = sp / (float)np_, cn = sn / (float)nn_, ci = si / (float)np_;
+        const float t1 = (cp - cn) + b, t2 = (cp - ci) + b;
+        const float h1 = t1 > 0.0f ? t1 : (t1 != t1 ? t1 : 0.0f), h2 = t2 > 0.0f ? t2 : (t2 != t2 ? t2 : 0.0f);
+        const float li = h1 + lamb * h2;
+        loss = loss + li;
+        if (per_sample) {
+            float *o = per_sample + (long)i * 8;
+            o[0] = cp; o[1] = cn; o[2] = ci; o[3] = t1; o[4] = t2; o[5] = (float)np_; o[6] = (float)nn_; o[7] = li;
+        }
+    }
+    return loss;
+}
 /* all moments of one video for one query, written in generate_moments order */
 static inline void video_moments(const float *dist, int n, float *out)
 {

@@ -447,3 +447,24 @@ def test_gemm_ping_pong_variant_is_bit_identical(vfr):
         vfr.set_option("gemm_pp", 0)
         vfr.set_option("lstm_tile", 0)
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,nl", [("plain", False), ("normalized", True)])
+def test_ranking_loss_forward_backward(vfr, oracle, golden, tag, nl):
+    """Trainer.ranking_loss on the device: forward == oracle bits (and the reference within 1e-6), autograd gradients ==
+    the reference's autograd within 1e-5."""
+    from vfr_amd import losses
+    g = golden("g7_ranking_loss.npz")
+    posit, intra, inter, lang, maskp, maskn = synth.ranking_batch(41)
+    t = [dev(a).clone().requires_grad_(True) for a in (posit, intra, inter, lang)]
+    loss, n = losses.ranking_loss(*t, dev(maskp), dev(maskn), normalize_loss=nl)
+    (loss * 1.0).backward()
+    assert n == int(g[f"n_{tag}"])
+    assert loss.item() == pytest.approx(float(g[f"loss_{tag}"]), rel=1e-6)
+    if not nl:
+        want, _ = oracle.ranking_loss(posit, intra, inter, lang, maskp, maskn)
+        assert np.float32(loss.item()) == want                                  # bit-exact forward
+    for name, x in zip(("posit", "intra", "inter", "lang"), t):
+        # (grad_lang sums ~15 signed row terms per element: different summation order, so an absolute floor too)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"grad_{name}_{tag}"], rtol=2e-5, atol=2e-7)

@@ -136,3 +136,17 @@ def test_validate_epoch_on_cpu_device_matches_reference_scalars(tag, clips, size
     vi, li = ds.iterators()
     got = vevaluate.validate_epoch(make_model(p["sd"]), vi, li, ds.annotations, "cpu", size=size)
     _check_validate(got, ref)
+
+
+@pytest.mark.parametrize("tag,nl", [("plain", False), ("normalized", True)])
+def test_ranking_loss_cpu_device_matches_reference(golden, tag, nl):
+    """losses.ranking_loss on CPU tensors: the reference's value, n_samples and autograd gradients."""
+    from vfr_amd import losses, synth
+    g = golden("g7_ranking_loss.npz")
+    posit, intra, inter, lang, maskp, maskn = synth.ranking_batch(41)
+    t = [torch.from_numpy(a).clone().requires_grad_(True) for a in (posit, intra, inter, lang)]
+    loss, n = losses.ranking_loss(*t, torch.from_numpy(maskp), torch.from_numpy(maskn), normalize_loss=nl)
+    loss.backward()
+    assert n == int(g[f"n_{tag}"]) and loss.item() == pytest.approx(float(g[f"loss_{tag}"]), rel=1e-6)
+    for name, x in zip(("posit", "intra", "inter", "lang"), t):
+        np.testing.assert_allclose(x.grad.numpy(), g[f"grad_{name}_{tag}"], rtol=1e-5, atol=1e-8)

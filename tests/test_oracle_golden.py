@@ -133,3 +133,13 @@ def test_rank_of_matches_sort(oracle):
     got = oracle.rank_of(Q, V, off, scores[np.arange(7), pick], pick)
     want = [int(np.where(order[q] == pick[q])[0][0]) for q in range(7)]
     assert got.tolist() == want
+
+
+def test_ranking_loss_oracle_vs_reference(golden, oracle):
+    """Trainer.ranking_loss (main.py:214-232): the oracle's canonical-order loss == the reference's within fp32 noise."""
+    from vfr_amd import synth
+    g = golden("g7_ranking_loss.npz")
+    loss, per = oracle.ranking_loss(*synth.ranking_batch(41))
+    assert int(g["n_plain"]) == per.shape[0] == 16
+    assert abs(float(loss) - float(g["loss_plain"])) <= 1e-6 * max(1.0, abs(float(g["loss_plain"])))
+    assert np.all(per[:, 5] > 0) and np.all(per[:, 6] > 0)

@@ -273,6 +273,30 @@ def g6_validate_epoch():
     print("G6", {k: v["scalars"].get("MedianRank") for k, v in out.items()})
 
 
+def g7_ranking_loss():
+    """Trainer.ranking_loss (model/main.py:214-232): loss value and autograd gradients, with and without normalize_loss."""
+    import matplotlib
+    matplotlib.use("Agg")
+    stub = types.ModuleType("torch.utils.tensorboard")
+    stub.SummaryWriter = object
+    sys.modules.setdefault("torch.utils.tensorboard", stub)
+    import main as ref_main  # noqa: E402  (reference)
+    out = {}
+    for tag, nl in (("plain", False), ("normalized", True)):
+        posit, intra, inter, lang, maskp, maskn = synth.ranking_batch(41)
+        t = [torch.from_numpy(a).clone().requires_grad_(True) for a in (posit, intra, inter, lang)]
+        tr = ref_main.Trainer.__new__(ref_main.Trainer)
+        tr.normalize_loss, tr.b, tr.lamb = nl, 0.1, 0.4
+        loss, n = tr.ranking_loss(t[0], t[1], t[2], t[3], torch.from_numpy(maskp), torch.from_numpy(maskn))
+        loss.backward()
+        out[f"loss_{tag}"] = np.float32(loss.item())
+        out[f"n_{tag}"] = np.int64(n)
+        for name, x in zip(("posit", "intra", "inter", "lang"), t):
+            out[f"grad_{name}_{tag}"] = x.grad.numpy()
+    np.savez_compressed(OUT / "g7_ranking_loss.npz", **out)
+    print("G7", {k: (v.shape if hasattr(v, "shape") and v.shape else v) for k, v in out.items() if k.startswith(("loss", "n_"))})
+
+
 if __name__ == "__main__":
     g3_moments_iou()
     g5_tokens()
@@ -282,3 +306,4 @@ if __name__ == "__main__":
     g2_scoring("ragged", "didemo")
     g2_scoring("n21", 21)
     g6_validate_epoch()
+    g7_ranking_loss()

@@ -43,6 +43,10 @@ SIGNATURES = {
     "vfr_score_topk_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i64, _i32, _vp, _vp, _i32,
                                   _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vfr_topk_merge_f32": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "vfr_ranking_loss_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "vfr_ranking_loss_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _sz, _vp]),
+    "vfr_ranking_loss_grad_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp,
+                                          _vp, _vp, _vp]),
     "vfr_frames_normalize_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "vfr_conv3x3_relu_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "vfr_maxpool2_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -368,3 +372,32 @@ def vgg_fc7(frames_thwc, cfg, conv_w, conv_b, fc6, fc7) -> torch.Tensor:
                                  f6b.data_ptr(), f7w.data_ptr(), f7b.data_ptr(), fc_dim, out.data_ptr(), ws.data_ptr(),
                                  nbytes, _stream()), "vfr_vgg_fc7_f32")
     return out
+
+
+def ranking_loss_forward(posit, intra, inter, lang, maskp, maskn, n_samples: int, b: float, lamb: float, eps: float = 1e-6):
+    """-> (loss [1] f32, workspace) ; the workspace (row distances, per-sample terms) feeds ranking_loss_backward."""
+    posit, intra, inter, lang = (_dev(x, torch.float32, n) for x, n in ((posit, "posit"), (intra, "intra"), (inter, "inter"),
+                                                                         (lang, "lang")))
+    maskp, maskn = _dev(maskp, torch.int64, "maskp"), _dev(maskn, torch.int64, "maskn")
+    P, Nn, D = posit.shape[0], intra.shape[0], posit.shape[1]
+    nbytes = lib().vfr_ranking_loss_workspace_bytes(P, Nn, n_samples)
+    ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=posit.device)
+    loss = torch.empty((1,), dtype=torch.float32, device=posit.device)
+    _check(lib().vfr_ranking_loss_f32(posit.data_ptr(), intra.data_ptr(), inter.data_ptr(), lang.data_ptr(), maskp.data_ptr(),
+                                      maskn.data_ptr(), P, Nn, n_samples, D, b, lamb, eps, loss.data_ptr(), ws.data_ptr(),
+                                      nbytes, _stream()), "vfr_ranking_loss_f32")
+    return loss, ws
+
+
+def ranking_loss_backward(posit, intra, inter, lang, maskp, maskn, n_samples: int, lamb: float, grad_loss, ws,
+                          eps: float = 1e-6):
+    posit, intra, inter, lang = (_dev(x, torch.float32, n) for x, n in ((posit, "posit"), (intra, "intra"), (inter, "inter"),
+                                                                         (lang, "lang")))
+    maskp, maskn = _dev(maskp, torch.int64, "maskp"), _dev(maskn, torch.int64, "maskn")
+    g = _dev(grad_loss.reshape(1), torch.float32, "grad_loss")
+    outs = [torch.empty_like(x) for x in (posit, intra, inter, lang)]
+    _check(lib().vfr_ranking_loss_grad_f32(posit.data_ptr(), intra.data_ptr(), inter.data_ptr(), lang.data_ptr(),
+                                           maskp.data_ptr(), maskn.data_ptr(), posit.shape[0], intra.shape[0], n_samples,
+                                           posit.shape[1], lamb, eps, g.data_ptr(), ws.data_ptr(), *[o.data_ptr() for o in outs],
+                                           _stream()), "vfr_ranking_loss_grad_f32")
+    return outs

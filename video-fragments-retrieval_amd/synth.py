@@ -130,3 +130,13 @@ def vgg_weights(cfg, in_hw, fc_dim: int, seed: int = 123):
     fc7 = ((rs.randn(fc_dim, fc_dim) * np.sqrt(2.0 / fc_dim)).astype(np.float32),
            (rs.randn(fc_dim) * 0.05).astype(np.float32))
     return conv_w, conv_b, fc6, fc7
+
+
+def ranking_batch(seed: int, P: int = 96, Nn: int = 80, S: int = 16, D: int = 100):
+    """Seeded stand-in for one triplet batch of ``Trainer.train_epoch`` (``model/main.py:48-61``): embeddings ~ N(0, 0.1),
+    masks = sorted sample ids covering every sample.  -> posit [P,D], intra [Nn,D], inter [P,D], lang [S,D], maskp, maskn."""
+    rs = np.random.RandomState(seed)
+    maskp = np.sort(np.concatenate([np.arange(S), rs.randint(0, S, P - S)])).astype(np.int64)
+    maskn = np.sort(np.concatenate([np.arange(S), rs.randint(0, S, Nn - S)])).astype(np.int64)
+    f = lambda n: (rs.randn(n, D) * 0.1).astype(np.float32)
+    return f(P), f(Nn), f(P), f(S), maskp, maskn
