@@ -336,6 +336,21 @@ def test_full_size_properties(vfr):
     # the 37th best moment has exactly 36 moments before it
     _, _, cnt = vfr.score_topk(Q, bank, 0, d[:, 36].contiguous(), i[:, 36].contiguous())
     assert bool((cnt[0] == 36).all())
+    # the whole fused pass (threshold ladder, flagged levels, merges, two rank keys) against the dense kernel + a sort, for a
+    # few queries over the FULL corpus, inside a 5000-query batch like the bench's
+    Qb = torch.randn(5000, 100, device=DEV)
+    Qb[:nq] = Q
+    sel = [0, 63, 64, 255]
+    dense = vfr.score_moments(Qb[sel].contiguous(), bank)                         # [4, 2.31M]
+    order = torch.argsort(dense, dim=1, stable=True)[:, :k]                     # stable: ties by moment id
+    rk_d = torch.stack([dense.gather(1, order[:, 36:37]).squeeze(1), dense.gather(1, order[:, 90:91]).squeeze(1)])
+    rk_i = torch.stack([order[:, 36], order[:, 90]])
+    full_rd = torch.full((2, 5000), 1e30, device=DEV); full_ri = torch.zeros((2, 5000), dtype=torch.int64, device=DEV)
+    full_rd[:, sel] = rk_d; full_ri[:, sel] = rk_i
+    db, ib, cb = vfr.score_topk(Qb, bank, k, full_rd.contiguous(), full_ri.contiguous())
+    assert torch.equal(ib[sel], order) and torch.equal(db[sel], dense.gather(1, order))
+    assert cb[0, sel].tolist() == [36] * 4 and cb[1, sel].tolist() == [90] * 4
+    assert torch.equal(ib[:nq], i) and torch.equal(db[:nq], d)                  # a query's result does not depend on its batch
     # spot-check against the dense kernel on the videos that own the winners
     top_vid = (i[:8, 0] // M).cpu().numpy()
     for q, v in enumerate(top_vid):
