@@ -950,7 +950,7 @@ static int kpl_for(int k) { return k <= 128 ? 4 : 8; }
 constexpr int PRE_VIDEOS = 32;
 constexpr int PRE_CHUNKS = 32;
 constexpr int PRE_LEVELS = 4;       // stage A keeps moments of at most this many clips
-static int pre_b_videos(int Nv) { const int b = Nv / 8; return b > 1024 ? 1024 : b; }
+static int pre_b_videos(int Nv) { if (opt_score_pre_b() > 0) return opt_score_pre_b() < Nv ? opt_score_pre_b() : Nv; const int b = Nv / 8; return b > 1024 ? 1024 : b; }
 
 struct TopkWs { unsigned long long *buf, *buf_pre, *pre_keys, *pre_keys2; int *cnt, *cnt_pre; unsigned long long *thr; size_t total; };
 static TopkWs carve_topk(void *base, int64_t Nq, int Nv, int k)

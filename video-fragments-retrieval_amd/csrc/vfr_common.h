@@ -19,6 +19,7 @@ inline hipStream_t as_stream(vfr_stream_t s) { return reinterpret_cast<hipStream
 int opt_gemm();
 int opt_score_fast();
 int opt_score_split();
+int opt_score_pre_b();
 int opt_lstm_tile();
 int opt_gemm_pp();
 
