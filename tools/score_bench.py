@@ -47,4 +47,5 @@ for fast in (1, 2, 0):
     timed(f"[{tag}] rank x2 only (selective keys)", lambda: _vfr.score_topk(Q, bank, 0, rd, ri, workspace=ws))
     timed(f"[{tag}] rank x2 only (median keys)", lambda: _vfr.score_topk(Q, bank, 0, mid_d, mid_id, workspace=ws))
     timed(f"[{tag}] top-100 + rank x2 (median keys)", lambda: _vfr.score_topk(Q, bank, 100, mid_d, mid_id, workspace=ws))
+    timed(f"[{tag}] top-100 + rank x2 (selective keys)", lambda: _vfr.score_topk(Q, bank, 100, rd, ri, workspace=ws))
     timed(f"[{tag}] top-1 only", lambda: _vfr.score_topk(Q, bank, 1, workspace=ws))

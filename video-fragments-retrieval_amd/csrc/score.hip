@@ -477,6 +477,22 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
         for (int L = 1; L <= NT; ++L) hix_t[L - 1] = active ? 0xFFFFFFFFu : 0u;       // thr = +inf: everything passes
     }
     bool dirty = false;
+    // Whole-video skip.  Every moment's score is a mean of clip distances, so score >= dmin * (1 - 21 * 2^-24) with
+    // dmin = the video's smallest clip distance (rounding is monotone: the chain sum of L values >= dmin is >= the chain sum
+    // of L copies of dmin, which is within (L-1) roundings of L * dmin; the division adds one more).  If dmin exceeds every
+    // bound this lane compares scores with -- its rank keys' distances and its top-k threshold distance -- by that margin, the
+    // video holds no candidate, nothing below a rank key and no tie for this query; when that is true for all 64 lanes the
+    // moment triangle is skipped.  Only the rank-only instantiation (TOPK = false: what evaluate() runs) carries the test: with
+    // a trained model its rank keys sit in the far tail of the distribution and most videos are skipped (9.7 -> 8.7 ms with keys
+    // at the 50th / 100th best moment).  In the fused top-k launches the ladder's threshold is ~10x looser than the final
+    // k-th key, some lane of 64 almost always has a candidate, and the test (+1.5 %) would be pure cost there.  (A second
+    // triangle instantiation without the rank half, for videos whose rank keys clear but whose top-k threshold does not, was
+    // measured too: -7 % for selective keys, +2 % on the bench from the extra register pressure: not kept.)
+    float rank_bound = 0.0f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { const float x = active ? rank_dist[r * a.Nq + qi] : 0.0f; rank_bound = x > rank_bound ? x : rank_bound; }
+    constexpr float SKIP_MARGIN = 1.000004f;
+    const float skipb = active ? rank_bound * SKIP_MARGIN : 0.0f;
 
     float4 pre[NLD];                                  // next group's rows, in flight while this group is computed
     auto gload = [&](int64_t row) {                   // rows [row, row+NC) of V -> registers (coalesced 16 B/lane)
@@ -590,6 +606,12 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
         float d[NT], sums[NT];
 #pragma unroll
         for (int c = 0; c < NT; ++c) d[c] = (EXACT || c < n) ? ds[c * 64 + lane] : __builtin_inff();
+        if (!TOPK) {
+            float dmin = d[0];
+#pragma unroll
+            for (int c = 1; c < NT; ++c) dmin = d[c] < dmin ? d[c] : dmin;
+            if (__ballot(!(dmin > skipb)) == 0) continue;          // no lane can see a score at or below any of its bounds
+        }
         // The triangle is branch-free: per moment one add, and per rank key u = bits(sum) - LOX, whose sign bit IS
         // "score < key" (both operands <= bits(+inf)), shifted into a per-level bit collector (v_alignbit; one popcount per level).  The top-k filter and the tie test
         // need only each level's MINIMUM of bits(sum) resp. u (v_min3: half an instruction per moment), folded once per
