@@ -443,7 +443,9 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #pragma unroll
             for (int k4 = 0; k4 < NS; ++k4) {
                 const int sn = k4 + DEPTH;                   // slice whose fragments are fetched now
+#ifndef VFR_GEMM_NOSYNC
                 if (sn == NS) __syncthreads();               // K-tile kt+1 (written at slice 1) is visible from here on
+#endif
                 if (sn < NS) frag_read(cb, sn, sn % RING);
                 else         frag_read(nb, sn - NS, sn % RING);    // (past the last K-tile: stale data, never used)
                 __builtin_amdgcn_sched_barrier(0);
