@@ -592,13 +592,25 @@ template <bool VEC, int MI = 2>
 __global__ __launch_bounds__(256, VFR_GEMM_NBUF == 1 ? 3 : 2) void gemm_nt_mfma(GemmArgs g) { gemm_nt_mfma_body<VEC, false, false, MI>(g); }
 
 template <bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp) { gemm_nt_mfma_body<VEC, false>(gp.p[blockIdx.z]); }
+__global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp)
+{
+    const GemmArgs g = gp.p[blockIdx.z];      // a private copy: fields read inside the K loop must not be re-fetched from the
+    gemm_nt_mfma_body<VEC, false>(g);         // kernarg array there (an s_load + lgkmcnt(0) would also drain the LDS reads)
+}
 
 __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true>(g); }
 
 template <int MI>
-__global__ __launch_bounds__(256, VFR_LSTM_WAVES) void lstm_step_mfma_pair(GemmPair gp) { gemm_nt_mfma_body<true, false, true, MI>(gp.p[blockIdx.z]); }
-__global__ __launch_bounds__(512, 2) void lstm_step_mfma_pair_pp(GemmPair gp) { gemm_nt_mfma_body<true, false, true, 2, true>(gp.p[blockIdx.z]); }
+__global__ __launch_bounds__(256, VFR_LSTM_WAVES) void lstm_step_mfma_pair(GemmPair gp)
+{
+    const GemmArgs g = gp.p[blockIdx.z];      // private copy, see gemm_nt_mfma_pair
+    gemm_nt_mfma_body<true, false, true, MI>(g);
+}
+__global__ __launch_bounds__(512, 2) void lstm_step_mfma_pair_pp(GemmPair gp)
+{
+    const GemmArgs g = gp.p[blockIdx.z];
+    gemm_nt_mfma_body<true, false, true, 2, true>(g);
+}
 template <bool VEC>
 __global__ __launch_bounds__(512, 2) void gemm_nt_mfma_pp(GemmArgs g) { gemm_nt_mfma_body<VEC, false, false, 2, true>(g); }
 
