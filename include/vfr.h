@@ -17,8 +17,8 @@
  *     (thread-local).  No exception, exit or abort crosses the boundary.
  *   - stateless and re-entrant; weights are passed per call (no hidden model handle), so
  *     load_state_dict()/.to() on the Python side keep working
- *   - numerics: every contraction is one k-ascending fp32 fma chain (what v_mfma_f32_32x32x2_f32
- *     computes), so results are bit-identical to oracle/vfr_oracle.c on any input
+ *   - numerics: every contraction is one k-ascending fp32 fma chain (what the fp32 MFMAs
+ *     compute), so results are bit-identical to oracle/vfr_oracle.c on any input
  */
 #ifndef VFR_H
 #define VFR_H

@@ -18,7 +18,7 @@
  * 1e-4.  The canonical rules, used everywhere below:
  *
  *   R1  every dot product / contraction is a single k-ascending chain acc = fmaf(a_k, b_k, acc)
- *       (this is exactly what v_mfma_f32_32x32x2_f32 computes; no split-K, no pairwise tree);
+ *       (this is exactly what the gfx950 fp32 MFMAs -- 32x32x2, 16x16x4 -- compute; no split-K, no pairwise tree);
  *   R2  biases are added after the chain, unless a chain is documented to start from a C-in;
  *   R3  row reductions that must be parallel on the GPU (sum of squares over 4096 features) use
  *       the fixed "64 lanes x strided float4 chunks + xor butterfly 32..1" tree (tree64 below);

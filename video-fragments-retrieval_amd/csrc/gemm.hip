@@ -4,7 +4,7 @@
 // exactly that chain and therefore the same bits:
 //   * gemm_nt_valu  -- LDS-tiled v_fma_f32 kernel (64x64 tile, 4x4 per thread); the simple form,
 //                      kept as the on-device cross-check (vfr_set_option("gemm", 0));
-//   * gemm_nt_mfma  -- v_mfma_f32_32x32x2_f32 kernel (128x128 tile, 4 waves x 2x2 MFMA tiles),
+//   * gemm_nt_mfma  -- v_mfma_f32_16x16x4_f32 kernel (128x128 or 64x128 tile, 4 waves x 4x4 / 2x4 MFMA tiles),
 //                      the production path: the MFMA's accumulate order over k IS the chain.
 // Used by: visual MLP (model/models.py:21-26), BiLSTM input/recurrent projections and lang_fc
 // (model/models.py:40-47), BERT-branch Linear (:31), VGG fc6/fc7 (get_rgb_features.py:126).
@@ -75,18 +75,18 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
 
 
 // ------------------------------------------------------------------------------------------------
-// MFMA chain kernel: 128x128 block tile, BK = 32, 4 waves as 2(M) x 2(N), each wave 2x2 tiles of
-// v_mfma_f32_32x32x2_f32 (64 accumulator VGPRs).  One MFMA consumes k, k+1 in order
-// (D = fma(a_k1, b_k1, fma(a_k0, b_k0, C))), and the k-loop below walks k strictly ascending, so every
-// output element is the same fp32 chain the VALU kernel and the oracle compute -- identical bits.
+// MFMA chain kernel: 128x128 (or 64x128) block tile, BK = 32, 4 waves as 2(M) x 2(N), each wave 4x4 (2x4) tiles of
+// v_mfma_f32_16x16x4_f32 (64 / 32 accumulator VGPRs).  One MFMA consumes k .. k+3 in order on top of its accumulator
+// (D = fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, C))))), and the k-loop below walks k strictly ascending, so every
+// output element is the same fp32 chain the VALU kernel and the oracle compute -- identical bits (the GPU tests compare with
+// array_equal).
 //
-// Operand fetch: LDS tiles are row-major [row][k] with a 36-float row stride (conflict-free for
-// ds_read_b128: 36r mod 64 hits 16 distinct 4-bank slots for any 16 rows distinct mod 16).  A lane reads
-// float4 = k..k+3 of its row; lane half h = lane>>5 uses (.x,.z) or (.y,.w) -- the MFMA wants
-// A[i = lane&31][k = h] -- so one 16-byte read feeds two MFMA k-steps.  Global->register prefetch of the
-// next K-tile is issued before the 64 MFMAs of the current tile and written to LDS after them.
-// fp32 MFMA runs at the fp32 vector rate (64 cycles per 32x32x2 per SIMD): this kernel is MFMA-pipe-bound,
-// staging has ~4096 cycles of cover per K-tile.
+// Operand fetch: LDS tiles are row-major [row][k] with a 36-float row stride.  A fragment is ONE dword per lane --
+// A[16*t + (lane & 15)][4*k4 + (lane >> 4)], exactly the 16x16x4 operand layout -- read with ds_read_b32
+// (bank = 36*r + q mod 64: 64 distinct banks).  The first version of this kernel used 32x32x2 tiles fed by ds_read_b128
+// fragments and a lane-half select; tools/ubench/mfma_rates.hip shows why it stalled at 121 TF on a 157 TF pipe: the 1 KB
+// LDS returns compete with the 32x32x2 accumulator write-back (64 B/clk), whatever the prefetch distance or spreading, while
+// 16x16x4 writes back half as much per flop.  fp32 MFMA runs at the fp32 vector rate (32 cycles per 16x16x4 per SIMD).
 // ------------------------------------------------------------------------------------------------
 #ifndef VFR_LSTM_NBUF
 #define VFR_LSTM_NBUF 2      // the fused LSTM step's own choice (experiment switch)
@@ -106,7 +106,6 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
 #ifndef VFR_GEMM_SETPRIO
 #define VFR_GEMM_SETPRIO 0
 #endif
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int MBM = 128, MBN = 128, MBK = 32, MLD = 36;
 
