@@ -483,3 +483,39 @@ def test_ranking_loss_forward_backward(vfr, oracle, golden, tag, nl):
     for name, x in zip(("posit", "intra", "inter", "lang"), t):
         # (grad_lang sums ~15 signed row terms per element: different summation order, so an absolute floor too)
         np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"grad_{name}_{tag}"], rtol=2e-5, atol=2e-7)
+
+
+@pytest.mark.gpu
+def test_fused_scorer_randomised_differential(vfr):
+    """A dozen random corpus shapes (uniform / ragged clip counts, tiny to mid-size, duplicated videos = exact ties, odd query
+    counts, k from 1 to 300): the fused pass == dense kernel + stable sort, rank counts exact (tools/score_fuzz.py is the
+    longer form of this)."""
+    rs = np.random.RandomState(11)
+    for it in range(12):
+        shape = ["n21", "n6", "ragged56", "ragged21"][it % 4]
+        nv = int(rs.choice([1, 3, 31, 33, 100, 257, 600, 1100]))
+        nq = int(rs.choice([1, 5, 63, 64, 65, 200]))
+        k = int(rs.choice([1, 10, 100, 128, 300]))
+        counts = {"n21": np.full(nv, 21), "n6": np.full(nv, 6), "ragged56": rs.choice([5, 6], nv),
+                  "ragged21": np.maximum(rs.randint(1, 22, nv), 21 * (np.arange(nv) == 0))}[shape]
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        g = torch.Generator(device=DEV).manual_seed(100 + it)
+        V = torch.randn((int(off[-1]), 100), device=DEV, generator=g) * 0.1
+        Q = torch.randn((nq, 100), device=DEV, generator=g) * 0.1
+        if it % 3 == 0 and nv > 2:
+            for v in range(1, nv):
+                if counts[v] == counts[0]:
+                    V[off[v]:off[v + 1]] = V[off[0]:off[1]]
+                    break
+        bank = vfr.VideoBank(V, dev(off))
+        dense = vfr.score_moments(Q, bank)
+        total = dense.shape[1]
+        order = torch.argsort(dense, dim=1, stable=True)
+        kk = min(k, total)
+        p0, p1 = int(rs.randint(0, total)), int(rs.randint(0, total))
+        rd = torch.stack([dense.gather(1, order[:, p0:p0 + 1]).squeeze(1), dense.gather(1, order[:, p1:p1 + 1]).squeeze(1)])
+        ri = torch.stack([order[:, p0], order[:, p1]])
+        d, i, c = vfr.score_topk(Q, bank, k, rd.contiguous(), ri.contiguous())
+        assert torch.equal(i[:, :kk], order[:, :kk]) and torch.equal(d[:, :kk], dense.gather(1, order[:, :kk])), (it, shape, nv, nq, k)
+        assert kk == k or bool((i[:, kk:] == -1).all())
+        assert c[0].tolist() == [p0] * nq and c[1].tolist() == [p1] * nq, (it, shape, nv, nq, k)
