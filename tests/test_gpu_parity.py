@@ -519,3 +519,81 @@ def test_fused_scorer_randomised_differential(vfr):
         assert torch.equal(i[:, :kk], order[:, :kk]) and torch.equal(d[:, :kk], dense.gather(1, order[:, :kk])), (it, shape, nv, nq, k)
         assert kk == k or bool((i[:, kk:] == -1).all())
         assert c[0].tolist() == [p0] * nq and c[1].tolist() == [p1] * nq, (it, shape, nv, nq, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pinned", [True, False])
+def test_feature_store_streamed_encode_is_bit_identical(vfr, oracle, pinned, tmp_path):
+    """the packed store + chunked H2D overlapped with the clip encoder (engine.encode_clips_streamed)
+    == the one-launch encoder on the same rows, bit for bit (chunk sizes chosen to give ragged, odd chunk counts), and
+    == the oracle on a sample of videos."""
+    from vfr_amd import engine
+    from vfr_amd.store import FeatureStore
+    counts = synth.clip_counts(700, "didemo", seed=21)
+    seg, ctx = synth.video_features(counts, 4096, seed=21)
+    off = synth.clip_offsets(counts)
+    names = [f"v{i}" for i in range(len(counts))]
+    FeatureStore.write(tmp_path / "c.vfs", names, off, ctx, seg)
+    st = FeatureStore.open(tmp_path / "c.vfs", pin=pinned)
+    assert st.seg.is_pinned() == pinned and np.array_equal(st.seg.numpy(), seg)
+    model = make_model(synth.model_weights(4096, seed=21)).to(DEV)
+    ops = engine.ops_for(DEV)
+    whole = model.encode_clips(st.seg.to(DEV), st.ctx.to(DEV), st.clip_off.to(DEV))
+    for chunk in (257, 1000, 4096):
+        part = engine.encode_clips_streamed(ops, model, st.seg, st.ctx, st.clip_off.numpy(), DEV, chunk_clips=chunk)
+        assert torch.equal(part, whole), chunk
+    sd = {k: v.cpu().numpy() for k, v in model.state_dict().items()}
+    v0, v1 = 300, 308
+    want = oracle.visual_mlp(seg[off[v0]:off[v1]], ctx[v0:v1], (off[v0:v1 + 1] - off[v0]).astype(np.int32),
+                             sd["visual_fc.0.weight"], sd["visual_fc.0.bias"], sd["visual_fc.2.weight"], sd["visual_fc.2.bias"])
+    assert np.array_equal(whole[off[v0]:off[v1]].cpu().numpy(), want)
+    # through build_corpus: a host bank above the streaming threshold takes the streamed path
+    old = engine.STREAM_CHUNK_CLIPS
+    engine.STREAM_CHUNK_CLIPS = 512
+    try:
+        shard = engine.build_corpus(model, st.feature_bank(), DEV, ops)
+    finally:
+        engine.STREAM_CHUNK_CLIPS = old
+    assert torch.equal(shard.bank.emb, whole)
+
+
+@pytest.mark.gpu
+def test_feature_store_packed_on_gpu_feeds_evaluate(vfr, oracle, tmp_path):
+    """FeatureStore.from_npy pools with the HIP kernel (== oracle bits); CustomDataset then opens the .vfs instead of the
+    .npy files and evaluate() gives the same dict on the device as on the CPU path."""
+    from vfr_amd import data as vdata
+    from vfr_amd import evaluate as vevaluate
+    from vfr_amd.store import FeatureStore
+    d = tmp_path / "features_vgg19"
+    d.mkdir()
+    lengths = (150, 138, 125, 112, 60, 25, 7)
+    names = [f"vid{T}" for T in lengths]
+    for T in lengths:
+        np.save(d / f"vgg19_ft_vid{T}.npy", np.random.RandomState(2000 + T).rand(T, 4096).astype(np.float32))
+    st = FeatureStore.from_npy(tmp_path / "features_vgg19.vfs", names, str(tmp_path), "vgg19", "avg", pool_device=DEV,
+                               chunk_videos=3)
+    for T, name in zip(lengths, names):
+        oseg, octx = oracle.segment_pool_norm(np.load(d / f"vgg19_ft_{name}.npy"), 25, "avg")
+        seg_v, ctx_v = st.video_rows(name)
+        assert np.array_equal(seg_v.numpy(), oseg) and np.array_equal(ctx_v.numpy(), octx)
+    words = [f"w{i}" for i in range(1, 40)]
+    with open(tmp_path / "glove.6B.100d.txt", "w") as fh:
+        for i, w in enumerate(words + ["unk"]):
+            fh.write(w + " " + " ".join([f"{0.01 * (i + 1):.2f}"] * 100) + "\n")
+    wi = vdata.WordIndexer(str(tmp_path))
+    rs = np.random.RandomState(4)
+    annots = {q: dict(video=names[q % len(names)], description=" ".join(rs.choice(words, size=rs.randint(1, 12))),
+                      times=[[0, 0], [0, 0], [0, 1]]) for q in range(21)}
+    ds = vdata.CustomDataset(names, annots, str(tmp_path), "vgg19", word_indexer=wi, validate=True)
+    assert ds.store is not None
+
+    def iters():
+        vi = torch.utils.data.DataLoader(ds, shuffle=False, collate_fn=vdata.validate_collate,
+                                         batch_sampler=vdata.VideoBatchSampler(names, ds.num_segments_info))
+        li = torch.utils.data.DataLoader(ds, shuffle=False, collate_fn=vdata.validate_collate,
+                                         batch_sampler=vdata.LanguageBatchSampler(annots, ds.num_segments_info))
+        return vi, li
+    model = make_model(synth.model_weights(4096, vocab=wi.get_items_count(), seed=9))
+    cpu = vevaluate.evaluate(model, *iters(), annots, "cpu")
+    gpu = vevaluate.evaluate(model.to(DEV), *iters(), annots, DEV)
+    assert gpu == cpu

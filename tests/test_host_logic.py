@@ -150,3 +150,68 @@ def test_ranking_loss_cpu_device_matches_reference(golden, tag, nl):
     assert n == int(g[f"n_{tag}"]) and loss.item() == pytest.approx(float(g[f"loss_{tag}"]), rel=1e-6)
     for name, x in zip(("posit", "intra", "inter", "lang"), t):
         np.testing.assert_allclose(x.grad.numpy(), g[f"grad_{name}_{tag}"], rtol=1e-5, atol=1e-8)
+
+
+def _npy_corpus(td, lengths=(150, 138, 125, 112)):
+    d = Path(td) / "features_vgg19"
+    d.mkdir()
+    names = []
+    for T in lengths:
+        x = np.random.RandomState(1000 + T).rand(T, 4096).astype(np.float32)
+        x[x < 0.3] = 0.0
+        np.save(d / f"vgg19_ft_vid{T}.npy", x)
+        names.append(f"vid{T}")
+    return names
+
+
+@pytest.mark.parametrize("mode", ["avg", "max"])
+def test_feature_store_round_trip_and_dataset_equivalence(golden, mode):
+    """store.FeatureStore: packing the extractor's .npy files gives the reference's pooled rows (g4),
+    and a dataset opened over the packed file is indistinguishable from one that pooled the .npy files itself."""
+    from vfr_amd.store import FeatureStore
+    g = golden("g4_pooling.npz")
+    with tempfile.TemporaryDirectory() as td:
+        names = _npy_corpus(td)
+        plain = vdata.CustomDataset(names, {}, td, "vgg19", pooling=mode, pool_device="cpu")
+        st = FeatureStore.from_npy(Path(td) / "features_vgg19.vfs", names, td, "vgg19", mode, pool_device="cpu")
+        assert (st.Nv, st.C, st.F) == (4, 22, 4096) and st.videos == names
+        assert st.clip_off.tolist() == [0, 6, 12, 17, 22] and st.num_segments_info == plain.num_segments_info
+        for T, name in zip((150, 138, 125, 112), names):
+            seg_v, ctx_v = st.video_rows(name)
+            np.testing.assert_allclose(seg_v.numpy(), g[f"seg_{mode}_{T}"], rtol=0, atol=3e-7)
+            np.testing.assert_allclose(ctx_v.numpy(), g[f"ctx_{mode}_{T}"], rtol=0, atol=3e-7)
+        packed = vdata.CustomDataset(names, {}, td, "vgg19", pooling=mode, pool_device="cpu")     # finds the .vfs
+        assert packed.store is not None and packed.num_segments_info == plain.num_segments_info
+        for name in names:
+            n = plain.num_segments_info[name]
+            assert torch.equal(packed.make_visual_features(name, 0, n - 1), plain.make_visual_features(name, 0, n - 1))
+        a, b = packed.feature_bank(), plain.feature_bank()
+        assert torch.equal(a.seg, b.seg) and torch.equal(a.ctx, b.ctx) and torch.equal(a.clip_off, b.clip_off)
+        assert a.seg.data_ptr() == st.feature_bank().seg.data_ptr() or a.seg.untyped_storage().size() >= 4 * 22 * 4096
+        sub = [names[2], names[0]]                                                              # another order: gathered
+        a, b = packed.feature_bank(sub), plain.feature_bank(sub)
+        assert a.videos == sub and torch.equal(a.seg, b.seg) and torch.equal(a.ctx, b.ctx) and a.clip_off.tolist() == [0, 5, 11]
+        with pytest.raises(ValueError):
+            vdata.CustomDataset(names, {}, td, "vgg19", pooling="max" if mode == "avg" else "avg", pool_device="cpu")
+
+
+def test_feature_store_rejects_damaged_files():
+    from vfr_amd.store import FeatureStore
+    with tempfile.TemporaryDirectory() as td:
+        p = Path(td) / "s.vfs"
+        rs = np.random.RandomState(0)
+        FeatureStore.write(p, ["a", "b"], [0, 2, 5], rs.rand(2, 8), rs.rand(5, 8))
+        st = FeatureStore.open(p)
+        assert st.seg.shape == (5, 8) and st.counts.tolist() == [2, 3]
+        raw = p.read_bytes()
+        (Path(td) / "cut.vfs").write_bytes(raw[:len(raw) - 4096])
+        (Path(td) / "magic.vfs").write_bytes(b"NOTSTORE" + raw[8:])
+        for bad in ("cut.vfs", "magic.vfs"):
+            with pytest.raises(ValueError):
+                FeatureStore.open(Path(td) / bad)
+        with pytest.raises(ValueError):
+            FeatureStore.write(p, ["a", "a"], [0, 2, 5], rs.rand(2, 8), rs.rand(5, 8))
+        with pytest.raises(ValueError):
+            FeatureStore.write(p, ["a", "b"], [0, 2, 4], rs.rand(2, 8), rs.rand(5, 8))
+        FeatureStore.write(p, [], [0], np.zeros((0, 8)), np.zeros((0, 8)))                       # empty corpus
+        assert FeatureStore.open(p).feature_bank().seg.shape[0] == 0

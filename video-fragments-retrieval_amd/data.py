@@ -145,11 +145,24 @@ class CustomDataset(Dataset):
         self.validate, self.pooling = validate, pooling
         self.pool_device = pool_device if pool_device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
         self.num_segments_info, self.video_features, self.lang_features = {}, {}, {}
+        self.store = None
         self.load_video_features(videos)
         self.load_lang_features(annotations)
 
     def load_video_features(self, videos):
         F = FEATURE_DIM[self.ft_type]
+        packed = Path(self.ft_directory) / f"features_{self.ft_type}.vfs"
+        if packed.exists():                         # packed store written by store.FeatureStore: no pooling, no copies
+            from .store import FeatureStore
+            self.store = FeatureStore.open(packed)
+            if self.store.F != F or self.store.meta["pooling"] != self.pooling:
+                raise ValueError(f"{packed}: built for F={self.store.F}, pooling={self.store.meta['pooling']}")
+            for video in videos:
+                seg_v, ctx_v = self.store.video_rows(video)
+                self.video_features[video] = dict(segment_features=seg_v.numpy(), context_features=ctx_v.numpy(),
+                                                  num_segments=int(seg_v.shape[0]))
+                self.num_segments_info[video] = int(seg_v.shape[0])
+            return
         arrays = []
         for video in videos:
             path = Path(self.ft_directory) / f"features_{self.ft_type}" / f"{self.ft_type}_ft_{video}.npy"
@@ -188,6 +201,8 @@ class CustomDataset(Dataset):
 
     def feature_bank(self, videos=None) -> FeatureBank:
         videos = list(self.video_features) if videos is None else list(videos)
+        if getattr(self, "store", None) is not None:
+            return self.store.feature_bank(videos)
         seg = np.concatenate([np.asarray(self.video_features[v]["segment_features"], np.float32) for v in videos])
         ctx = np.stack([np.asarray(self.video_features[v]["context_features"], np.float32) for v in videos])
         counts = [self.num_segments_info[v] for v in videos]

@@ -88,12 +88,65 @@ def build_corpus(model, feature_bank, device, ops=None, rank=0, world=1) -> Corp
     mom_off_all = np.concatenate([[0], np.cumsum(counts * (counts + 1) // 2)]).astype(np.int64)
     lo, hi = shard_range(len(counts), rank, world)
     c0, c1 = int(off_all[lo]), int(off_all[hi])
-    seg = feature_bank.seg[c0:c1].to(device)
-    ctx = feature_bank.ctx[lo:hi].to(device)
     clip_off = torch.from_numpy((off_all[lo:hi + 1] - c0).astype(np.int32)).to(device)
-    emb = ops.encode_clips(model, seg, ctx, clip_off)
+    if feature_bank.seg.device.type == "cpu" and torch.device(device).type == "cuda" and c1 - c0 > STREAM_CHUNK_CLIPS:
+        emb = encode_clips_streamed(ops, model, feature_bank.seg[c0:c1], feature_bank.ctx[lo:hi],
+                                    off_all[lo:hi + 1] - c0, device)
+    else:
+        emb = ops.encode_clips(model, feature_bank.seg[c0:c1].to(device), feature_bank.ctx[lo:hi].to(device), clip_off)
     bank = ops.make_bank(emb, clip_off, int(mom_off_all[lo]))
     return CorpusShard(bank, lo, hi, counts, mom_off_all, torch.device(device))
+
+
+STREAM_CHUNK_CLIPS = 1 << 15        # 512 MB of fp32 VGG rows per staging buffer; >= 1024 GEMM tiles per chunk
+
+
+def encode_clips_streamed(ops, model, seg, ctx, off, device, chunk_clips=None):
+    """Clip embeddings of host-resident pooled rows, H2D copy overlapped with the clip encoder.
+
+    ``seg [C, F]`` / ``ctx [Nv, F]`` are host tensors (page-locked ones -- ``store.FeatureStore.pin()`` -- copy
+    asynchronously at PCIe rate; pageable ones still work, through the runtime's staging), ``off`` the CSR offsets
+    (host, int64, ``off[0] == 0``).  Videos are grouped into chunks of at most ``chunk_clips`` clips; chunk i+1 is
+    copied on a side stream into the other of two device staging buffers while chunk i is encoded, so the step
+    costs max(copy, encode) instead of their sum and the features never have to be resident in HBM as a whole.
+    Each output row depends on its own clip and its video's context row only, so the result is bit-identical to
+    the one-launch path."""
+    chunk_clips = chunk_clips or STREAM_CHUNK_CLIPS
+    off = np.asarray(off, np.int64)
+    Nv, C, F = len(off) - 1, int(off[-1]), int(seg.shape[1])
+    bounds, v0 = [], 0
+    while v0 < Nv:                                              # greedy video-aligned chunks
+        v1 = int(np.searchsorted(off, off[v0] + chunk_clips, side="right")) - 1
+        v1 = min(max(v1, v0 + 1), Nv)
+        bounds.append((v0, v1))
+        v0 = v1
+    max_c = max(int(off[b] - off[a]) for a, b in bounds)
+    max_v = max(b - a for a, b in bounds)
+    dev = torch.device(device)
+    main, side = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+    seg_buf = [torch.empty((max_c, F), dtype=torch.float32, device=dev) for _ in range(2)]
+    ctx_buf = [torch.empty((max_v, F), dtype=torch.float32, device=dev) for _ in range(2)]
+    off_dev = torch.from_numpy(off.astype(np.int32)).to(dev)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    free = [torch.cuda.Event() for _ in range(2)]
+    side.wait_stream(main)
+    out = None
+    for i, (a, b) in enumerate(bounds):
+        s = i & 1
+        c0, c1 = int(off[a]), int(off[b])
+        with torch.cuda.stream(side):
+            if i >= 2:
+                side.wait_event(free[s])                        # the encoder is done with this staging buffer
+            seg_buf[s][:c1 - c0].copy_(seg[c0:c1], non_blocking=True)
+            ctx_buf[s][:b - a].copy_(ctx[a:b], non_blocking=True)
+            ready[s].record(side)
+        main.wait_event(ready[s])
+        part = ops.encode_clips(model, seg_buf[s][:c1 - c0], ctx_buf[s][:b - a], off_dev[a:b + 1] - c0)
+        free[s].record(main)
+        if out is None:
+            out = torch.empty((C, part.shape[1]), dtype=torch.float32, device=dev)
+        out[c0:c1] = part
+    return out
 
 
 def corpus_from_embeddings(emb, counts, device, ops=None, rank=0, world=1) -> CorpusShard:
