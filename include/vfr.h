@@ -123,6 +123,24 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
  * [G, Nq, k] -> out [Nq, k], same (distance, id) order.                                        */
 int vfr_topk_merge_f32(const float *part_dist, const int64_t *part_idx, int G, int64_t Nq, int k, float *out_dist,
                        int64_t *out_idx, vfr_stream_t stream);
+/* The same exchange with the lists in the form the ranks send them: one int64 key per entry,
+ * (fp32 bits of the distance << 32) | moment id, whose signed order is the (distance, id) order;
+ * VFR_KEY_EMPTY = (+inf, 0xffffffff) marks an unused slot.  pack: (dist, idx) [n] -> keys [n]
+ * (idx < 0 -> empty).  merge: part_keys [G, Nq, k] -> out_dist/out_idx [Nq, k] (both or neither)
+ * and/or out_keys [Nq, k] (nullable) -- the merged list as keys, whose column k-1 is the
+ * threshold seed of the next pass and which can be merged again without repacking.             */
+#define VFR_KEY_EMPTY 0x7F800000FFFFFFFFll
+int vfr_topk_pack_keys(const float *dist, const int64_t *idx, int64_t n, int64_t *keys, vfr_stream_t stream);
+int vfr_topk_merge_keys(const int64_t *part_keys, int G, int64_t Nq, int k, float *out_dist, int64_t *out_idx,
+                        int64_t *out_keys, vfr_stream_t stream);
+/* a12  position of the first ground-truth-positive moment (model/evaluate.py:67-77,
+ * np.where(labels[order])[0][0]) needs that moment's key: keys[r, sel[s]] = min over m < M with
+ * labels[r, s, m] != 0 of (own_scores[s, m], id_base[s] + m); every other entry of keys [R, Nq]
+ * (queries whose video lives on another rank, queries without a positive) = VFR_KEY_EMPTY.
+ * own_scores [n_sel, score_stride] from vfr_score_own_f32, labels uint8 [R, n_sel, label_stride]. */
+int vfr_gt_best_keys_f32(const float *own_scores, int64_t n_sel, int M, int score_stride, const uint8_t *labels, int R,
+                         int label_stride, const int64_t *id_base, const int64_t *sel, int64_t Nq, int64_t *keys,
+                         vfr_stream_t stream);
 
 /* ---- a1  frame normalisation: DiDeMoDataset.__getitem__ tail, get_rgb_features.py:64-69
  * THWC uint8 -> TCHW fp32, ((x/255) - mean[c]) / std[c] with the ImageNet constants (:34-35)    */

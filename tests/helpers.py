@@ -56,3 +56,64 @@ def make_model(sd, feat_dim=4096, hidden=1000, normalize_lang=False):
 
 def lstm_of(sd):
     return {k[len("lstm."):]: v for k, v in sd.items() if k.startswith("lstm.")}
+
+
+class ThreadRanks:
+    """N ranks as N threads of this process sharing one device: the collectives engine.py uses (all_gather, all_reduce,
+    barrier), implemented with a thread barrier.  Lets the world > 1 code path run through the real kernels on a one-GPU
+    box (all threads launch on the same stream, so host-side launch order is device order)."""
+
+    class ReduceOp:
+        SUM, MIN, MAX = "sum", "min", "max"
+
+    def __init__(self, world):
+        import threading
+        self.world, self.slots = world, [None] * world
+        self.bar = threading.Barrier(world)
+        self.tls = threading.local()
+
+    def _rank(self):
+        return self.tls.rank
+
+    def barrier(self):
+        self.bar.wait()
+
+    def all_gather(self, parts, t):
+        self.slots[self._rank()] = t
+        self.bar.wait()
+        for p, s in zip(parts, list(self.slots)):
+            p.copy_(s)
+        self.bar.wait()
+
+    def all_reduce(self, t, op=None):
+        self.slots[self._rank()] = t.clone()
+        self.bar.wait()
+        allv = torch.stack(list(self.slots))
+        red = allv.sum(0) if op == "sum" else (allv.min(0).values if op == "min" else allv.max(0).values)
+        self.bar.wait()
+        t.copy_(red)
+
+    def run(self, fn):
+        """fn(rank, world) on every rank; returns the list of results, re-raising the first failure."""
+        import threading
+        out, err = [None] * self.world, [None] * self.world
+
+        def body(r):
+            self.tls.rank = r
+            try:
+                out[r] = fn(r, self.world)
+            except BaseException as e:                      # noqa: BLE001 -- reported to the caller below
+                err[r] = e
+                self.bar.abort()
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for e in err:
+            if e is not None and not isinstance(e, __import__("threading").BrokenBarrierError):
+                raise e
+        for e in err:
+            if e is not None:
+                raise e
+        return out

@@ -597,3 +597,74 @@ def test_feature_store_packed_on_gpu_feeds_evaluate(vfr, oracle, tmp_path):
     cpu = vevaluate.evaluate(model, *iters(), annots, "cpu")
     gpu = vevaluate.evaluate(model.to(DEV), *iters(), annots, DEV)
     assert gpu == cpu
+
+
+@pytest.mark.gpu
+def test_exchange_key_helpers_match_cpu_provider(vfr):
+    """vfr_topk_pack_keys / vfr_topk_merge_keys / vfr_gt_best_keys_f32 (the exchange side of SURVEY 8e) against the
+    plain-torch CPU provider: unsorted lists, empty slots, duplicates across lists, G*k above and below the pool size."""
+    from vfr_amd import engine
+    cpu = engine.TorchCpuOps()
+    rs = np.random.RandomState(5)
+    for G, Nq, k in ((9, 130, 100), (3, 50, 300), (20, 33, 7), (1, 5, 1), (2, 70, 448)):
+        d = rs.rand(G, Nq, k).astype(np.float32)
+        d[rs.rand(G, Nq, k) < 0.1] = 0.25                                   # ties on the distance -> id decides
+        i = rs.randint(0, 5000, size=(G, Nq, k)).astype(np.int64)
+        i[rs.rand(G, Nq, k) < 0.2] = -1                                     # empty slots anywhere
+        if G > 1:
+            d[1], i[1] = d[0], i[0]                                         # a whole duplicated list
+        td, ti = torch.from_numpy(d), torch.from_numpy(i)
+        wk = cpu.pack_keys(td, ti)
+        gk = vfr.topk_pack_keys(td.to(DEV), ti.to(DEV))
+        assert torch.equal(gk.cpu(), wk)
+        wd, wi, wkeys = cpu.merge_keys(wk, True, True)
+        gd, gi, gkeys = vfr.topk_merge_keys(gk, True, True)
+        assert torch.equal(gkeys.cpu(), wkeys) and torch.equal(gi.cpu(), wi) and torch.equal(gd.cpu(), wd)
+        assert vfr.topk_merge_keys(gk, False, True)[2].equal(gkeys)
+        md, mi = vfr.topk_merge(td.to(DEV), ti.to(DEV))                     # (dist, idx) form: same kernel, other loader
+        assert torch.equal(mi.cpu(), wi) and torch.equal(md.cpu(), wd)
+    for R, n_sel, Ms, Ml, Nq in ((2, 300, 231, 231, 900), (11, 40, 21, 28, 40), (1, 1, 3, 3, 2), (2, 0, 6, 6, 10)):
+        sc = rs.rand(n_sel, Ms).astype(np.float32)
+        sc[:, Ms - 1] = np.inf
+        lab = rs.rand(R, n_sel, Ml) < 0.15
+        if n_sel:
+            lab[0, 0] = False                                                # a query without any positive
+        base = rs.randint(0, 1 << 20, size=n_sel).astype(np.int64)
+        sel = rs.permutation(Nq)[:n_sel].astype(np.int64)
+        want = cpu.gt_best_keys(torch.from_numpy(sc), torch.from_numpy(lab), torch.from_numpy(base), torch.from_numpy(sel), Nq)
+        if n_sel:
+            got = vfr.gt_best_keys(torch.from_numpy(sc).to(DEV), torch.from_numpy(lab).to(DEV),
+                                   torch.from_numpy(base).to(DEV), torch.from_numpy(sel).to(DEV), Nq)
+            assert torch.equal(got.cpu(), want)
+            assert int(got[0, sel[0]]) == engine.KEY_INF
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_evaluate_through_kernels_equals_single(vfr, world):
+    """engine's world > 1 flow (sample exchange -> seed -> main pass -> exchange -> merge; keys MIN, counts SUM; query
+    slices gathered) on the real kernels: N ranks as N threads of this process with thread-barrier collectives
+    (helpers.ThreadRanks).  Every rank's dict and top-k == the single-rank pass."""
+    from helpers import ThreadRanks
+    from vfr_amd import engine
+    from vfr_amd import evaluate as vevaluate
+    p = problem(700, 150, "didemo", seed=31)
+    ds = MemoryDataset(p["seg"], p["ctx"], p["counts"], p["tokens"], p["own"], p["times"])
+    model = make_model(p["sd"]).to(DEV)
+    want, (wd, wi) = vevaluate.evaluate(model, *ds.iterators(), ds.annotations, DEV, return_topk=100)
+    wv = vevaluate.validate_epoch(model, *ds.iterators(), ds.annotations, DEV, size=-1)
+    group = ThreadRanks(world)
+    old = engine._dist
+    engine._dist = lambda: group
+    try:
+        def body(rank, n):
+            torch.cuda.set_device(0)
+            res, (d, i) = vevaluate.evaluate(model, *ds.iterators(), ds.annotations, DEV, rank=rank, world=n, return_topk=100)
+            v = vevaluate.validate_epoch(model, *ds.iterators(), ds.annotations, DEV, size=-1, rank=rank, world=n)
+            return res, d.cpu(), i.cpu(), v
+        outs = group.run(body)
+    finally:
+        engine._dist = old
+    for res, d, i, v in outs:
+        assert res == want and v == wv
+        assert torch.equal(i, wi.cpu()) and torch.equal(d, wd.cpu())

@@ -43,6 +43,9 @@ SIGNATURES = {
     "vfr_score_topk_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i64, _i32, _vp, _vp, _i32,
                                   _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vfr_topk_merge_f32": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "vfr_topk_pack_keys": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "vfr_topk_merge_keys": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "vfr_gt_best_keys_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "vfr_ranking_loss_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "vfr_ranking_loss_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _sz, _vp]),
     "vfr_ranking_loss_grad_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp,
@@ -223,10 +226,10 @@ class VideoBank:
     """
 
     def __init__(self, emb: torch.Tensor, clip_off: torch.Tensor, id_base: int = 0, max_clips: int | None = None,
-                 total_moments: int | None = None, min_clips: int | None = None):
+                 total_moments: int | None = None, min_clips: int | None = None, mom_off: torch.Tensor | None = None):
         self.emb = _dev(emb, torch.float32, "emb")
         self.clip_off = _dev(clip_off, torch.int32, "clip_off")
-        self.mom_off = moment_offsets(self.clip_off)
+        self.mom_off = moment_offsets(self.clip_off) if mom_off is None else _dev(mom_off, torch.int64, "mom_off")
         self.num_videos = int(self.clip_off.numel() - 1)
         if max_clips is None or total_moments is None or min_clips is None:   # scalar D2H reads, skipped when the host knows
             n = self.clip_off[1:] - self.clip_off[:-1]
@@ -246,10 +249,11 @@ def slice_bank(bank: VideoBank, counts, v0: int, v1: int) -> VideoBank:
     off = np.concatenate([[0], np.cumsum(counts)])
     mom = np.concatenate([[0], np.cumsum(counts * (counts + 1) // 2)])
     sub = counts[v0:v1]
-    clip_off = torch.from_numpy((off[v0:v1 + 1] - off[v0]).astype(np.int32)).to(bank.emb.device)
-    return VideoBank(bank.emb[int(off[v0]):int(off[v1])], clip_off, bank.id_base + int(mom[v0]),
+    clip_off = bank.clip_off[v0:v1 + 1] if v0 == 0 else bank.clip_off[v0:v1 + 1] - bank.clip_off[v0]   # on the device
+    mom_off = bank.mom_off[v0:v1 + 1] if v0 == 0 else bank.mom_off[v0:v1 + 1] - bank.mom_off[v0]
+    return VideoBank(bank.emb[int(off[v0]):int(off[v1])], clip_off.contiguous(), bank.id_base + int(mom[v0]),
                      max_clips=int(sub.max()) if len(sub) else 0, total_moments=int(mom[v1] - mom[v0]),
-                     min_clips=int(sub.min()) if len(sub) else 0)
+                     min_clips=int(sub.min()) if len(sub) else 0, mom_off=mom_off.contiguous())
 
 
 def score_moments(Q: torch.Tensor, bank: VideoBank, eps: float = 1e-6) -> torch.Tensor:
@@ -317,6 +321,46 @@ def topk_merge(part_dist: torch.Tensor, part_idx: torch.Tensor):
     _check(lib().vfr_topk_merge_f32(pd.data_ptr(), pi.data_ptr(), G, Nq, k, od.data_ptr(), oi.data_ptr(), _stream()),
            "vfr_topk_merge_f32")
     return od, oi
+
+
+KEY_EMPTY = 0x7F800000FFFFFFFF     # VFR_KEY_EMPTY: (+inf, max id)
+
+
+def topk_pack_keys(dist: torch.Tensor, idx: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """(dist, idx) lists -> int64 exchange keys of the same shape (idx < 0 -> KEY_EMPTY)."""
+    d, i = _dev(dist, torch.float32, "dist"), _dev(idx, torch.int64, "idx")
+    keys = out if out is not None else torch.empty(d.shape, dtype=torch.int64, device=d.device)
+    if out is not None:
+        _dev(out, torch.int64, "out")
+    _check(lib().vfr_topk_pack_keys(d.data_ptr(), i.data_ptr(), d.numel(), keys.data_ptr(), _stream()), "vfr_topk_pack_keys")
+    return keys
+
+
+def topk_merge_keys(part_keys: torch.Tensor, want_lists: bool = True, want_keys: bool = False):
+    """[G,Nq,k] int64 key lists -> (dist [Nq,k] | None, idx [Nq,k] | None, keys [Nq,k] | None)."""
+    pk = _dev(part_keys, torch.int64, "part_keys")
+    G, Nq, k = pk.shape
+    od = torch.empty((Nq, k), dtype=torch.float32, device=pk.device) if want_lists else None
+    oi = torch.empty((Nq, k), dtype=torch.int64, device=pk.device) if want_lists else None
+    ok = torch.empty((Nq, k), dtype=torch.int64, device=pk.device) if want_keys else None
+    _check(lib().vfr_topk_merge_keys(pk.data_ptr(), G, Nq, k, _ptr(od), _ptr(oi), _ptr(ok), _stream()), "vfr_topk_merge_keys")
+    return od, oi, ok
+
+
+def gt_best_keys(own_scores: torch.Tensor, labels: torch.Tensor, id_base: torch.Tensor, sel: torch.Tensor, Nq: int):
+    """own_scores [n_sel, Ms] (``score_own``), labels bool/uint8 [R, n_sel, Ml], id_base / sel int64 [n_sel] ->
+    keys int64 [R, Nq]: best positive (score, id) per threshold and query, KEY_EMPTY elsewhere."""
+    sc = _dev(own_scores, torch.float32, "own_scores")
+    lab = labels.view(torch.uint8) if labels.dtype == torch.bool else labels
+    lab = _dev(lab, torch.uint8, "labels")
+    base, sel = _dev(id_base, torch.int64, "id_base"), _dev(sel, torch.int64, "sel")
+    R, n_sel, Ml = lab.shape
+    if sc.shape[0] != n_sel or base.numel() != n_sel or sel.numel() != n_sel:
+        raise RuntimeError("gt_best_keys: inconsistent shapes")
+    keys = torch.empty((R, Nq), dtype=torch.int64, device=sc.device)
+    _check(lib().vfr_gt_best_keys_f32(sc.data_ptr(), n_sel, min(sc.shape[1], Ml), sc.shape[1], lab.data_ptr(), R, Ml,
+                                      base.data_ptr(), sel.data_ptr(), Nq, keys.data_ptr(), _stream()), "vfr_gt_best_keys_f32")
+    return keys
 
 
 def frames_normalize(frames_thwc: torch.Tensor) -> torch.Tensor:

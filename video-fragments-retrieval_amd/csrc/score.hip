@@ -854,54 +854,124 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
     }
 }
 
-// merge G shard lists given as (dist, idx) arrays: [G, Nq, k] -> [Nq, k]   (after the all-gather, 8e)
-template <int KPL>
+// merge G shard lists [G, Nq, k] -> [Nq, k] (after the all-gather, 8e).  Lists arrive either as (dist, idx) arrays or as
+// the packed int64 keys the ranks exchange (KEY_EMPTY = (+inf, 0xffffffff) marks an unused slot).  Same LDS pool as the
+// task merge: all G*k keys are read as one flat sequence, CAP per round with the loads in flight together, and a key is
+// appended only if it beats the running k-th key -- after the first round almost nothing is, so a query costs ~2 sorts.
+constexpr unsigned long long KEY_EMPTY = 0x7F800000FFFFFFFFull;
+template <int KPL, bool PACKED>
 __global__ __launch_bounds__(256) void topk_merge_parts_kernel(const float *__restrict__ pd,
                                                                const int64_t *__restrict__ pi, int G, int64_t Nq,
                                                                int k, float *__restrict__ out_dist,
-                                                               int64_t *__restrict__ out_idx)
+                                                               int64_t *__restrict__ out_idx,
+                                                               int64_t *__restrict__ out_keys)
 {
     constexpr int CAP = KPL * 64;
-    const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wv;
     if (q >= Nq) return;
+    __shared__ unsigned long long pool_s[4][CAP];
+    unsigned long long *pool = pool_s[wv];
     unsigned long long key[KPL];
-#pragma unroll
-    for (int i = 0; i < KPL; ++i) key[i] = KEY_MAX;
+    unsigned long long thr = KEY_MAX;
     int fill = 0;
-    for (int g = 0; g < G; ++g) {
-        const float *d = pd + ((int64_t)g * Nq + q) * k;
-        const int64_t *ix = pi + ((int64_t)g * Nq + q) * k;
-        int off = 0;
-        while (off < k) {
-            if (fill == CAP) {
-                wave_sort<KPL>(key, lane);
+    auto lds_sync = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); };
+    auto sort_pool = [&](bool final_pass) {
+        lds_sync();
 #pragma unroll
-                for (int i = 0; i < KPL; ++i)
-                    if (i * 64 + lane >= k) key[i] = KEY_MAX;
-                fill = k;
-            }
-            const int room = CAP - fill, take = (k - off) < room ? (k - off) : room;
+        for (int i = 0; i < KPL; ++i) { const int e = i * 64 + lane; key[i] = e < fill ? pool[e] : KEY_MAX; }
+        wave_sort<KPL>(key, lane);
+        if (final_pass) return;
+        lds_sync();
 #pragma unroll
-            for (int i = 0; i < KPL; ++i) {
-                int e = i * 64 + lane;
-                if (e >= fill && e < fill + take) {
-                    int64_t id = ix[off + e - fill];
-                    key[i] = id < 0 ? KEY_MAX : make_key(d[off + e - fill], (unsigned)id);
+        for (int i = 0; i < KPL; ++i) { const int e = i * 64 + lane; if (e < k) pool[e] = key[i]; }
+        if (fill >= k) thr = key_at<KPL>(key, k - 1);
+        fill = fill < k ? fill : k;
+    };
+    const int total = G * k;
+    for (int done = 0; done < total; done += CAP) {
+        unsigned long long x[KPL];
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const int gi = done + i * 64 + lane;
+            x[i] = KEY_MAX;
+            if (gi < total) {
+                const int g = gi / k, off = gi - g * k;
+                const int64_t at = ((int64_t)g * Nq + q) * k + off;
+                if constexpr (PACKED) {
+                    const unsigned long long v = (unsigned long long)pi[at];
+                    x[i] = v >= KEY_EMPTY ? KEY_MAX : v;
+                } else {
+                    const int64_t id = pi[at];
+                    x[i] = id < 0 ? KEY_MAX : make_key(pd[at], (unsigned)id);
                 }
             }
-            fill += take; off += take;
+        }
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            if (fill + 64 > CAP) sort_pool(false);
+            const bool pass = x[i] < thr;                        // KEY_MAX (empty) never passes
+            const unsigned long long m = __ballot(pass);
+            if (pass) pool[fill + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = x[i];
+            fill += __builtin_popcountll(m);
         }
     }
-    wave_sort<KPL>(key, lane);
+    sort_pool(true);
 #pragma unroll
     for (int i = 0; i < KPL; ++i) {
         int e = i * 64 + lane;
         if (e < k) {
             const bool ok = key[i] != KEY_MAX;
-            out_dist[q * k + e] = ok ? __uint_as_float((unsigned)(key[i] >> 32)) : __builtin_inff();
-            out_idx[q * k + e] = ok ? (int64_t)(key[i] & 0xffffffffull) : -1;
+            if (out_dist) {
+                out_dist[q * k + e] = ok ? __uint_as_float((unsigned)(key[i] >> 32)) : __builtin_inff();
+                out_idx[q * k + e] = ok ? (int64_t)(key[i] & 0xffffffffull) : -1;
+            }
+            if (out_keys) out_keys[q * k + e] = (int64_t)(ok ? key[i] : KEY_EMPTY);
         }
+    }
+}
+
+// (dist, idx) lists -> the packed int64 keys the ranks exchange (one collective instead of two); idx < 0 -> KEY_EMPTY
+__global__ __launch_bounds__(256) void topk_pack_keys_kernel(const float *__restrict__ d, const int64_t *__restrict__ ix,
+                                                             int64_t n, int64_t *__restrict__ keys)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t id = ix[i];
+    keys[i] = (int64_t)(id < 0 ? KEY_EMPTY : make_key(d[i], (unsigned)id));
+}
+
+// best ground-truth-positive key per (threshold, query):  min over the labelled moments of the query's own video of
+// (score, global id)  (evaluate.py:67-77: the first positive in the sorted order).  One wave per selected query.
+__global__ __launch_bounds__(256) void gt_fill_keys_kernel(int64_t n, int64_t *__restrict__ keys)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = (int64_t)KEY_EMPTY;
+}
+__global__ __launch_bounds__(256) void gt_best_keys_kernel(const float *__restrict__ sc, int64_t n_sel, int M,
+                                                           int score_stride, const uint8_t *__restrict__ labels, int R,
+                                                           int label_stride, const int64_t *__restrict__ id_base,
+                                                           const int64_t *__restrict__ sel, int64_t Nq,
+                                                           int64_t *__restrict__ keys)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_sel) return;
+    const int64_t base = id_base[s], q = sel[s];
+    for (int r = 0; r < R; ++r) {
+        unsigned long long best = KEY_MAX;
+        const uint8_t *lab = labels + ((int64_t)r * n_sel + s) * label_stride;
+        for (int m = lane; m < M; m += 64)
+            if (lab[m]) {
+                const unsigned long long kk = make_key(sc[s * score_stride + m], (unsigned)(base + m));
+                best = kk < best ? kk : best;
+            }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(best, d, 64);
+            best = o < best ? o : best;
+        }
+        if (lane == 0) keys[(int64_t)r * Nq + q] = (int64_t)(best >= KEY_EMPTY ? KEY_EMPTY : best);
     }
 }
 
@@ -1199,21 +1269,67 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
     return VFR_OK;
 }
 
+static int launch_merge_parts(const float *pd, const int64_t *pi, bool packed, int G, int64_t Nq, int k, float *od,
+                              int64_t *oi, int64_t *okeys, vfr_stream_t stream)
+{
+    dim3 grid((unsigned)vfr::cdiv(Nq, 4)), block(256);
+    const int kpl = vfr::kpl_for(k);
+#define VFR_MERGE(KPL, PACKED) hipLaunchKernelGGL((vfr::topk_merge_parts_kernel<KPL, PACKED>), grid, block, 0, \
+                                                  vfr::as_stream(stream), pd, pi, G, Nq, k, od, oi, okeys)
+    if (packed) { if (kpl == 4) VFR_MERGE(4, true); else VFR_MERGE(8, true); }
+    else        { if (kpl == 4) VFR_MERGE(4, false); else VFR_MERGE(8, false); }
+#undef VFR_MERGE
+    VFR_CHECK_LAUNCH("topk_merge_parts_kernel");
+    return VFR_OK;
+}
+
 int vfr_topk_merge_f32(const float *part_dist, const int64_t *part_idx, int G, int64_t Nq, int k, float *out_dist,
                        int64_t *out_idx, vfr_stream_t stream)
 {
     VFR_REQUIRE(part_dist && part_idx && out_dist && out_idx && G > 0 && Nq >= 0 && k > 0, VFR_EINVAL,
                 "vfr_topk_merge_f32: bad argument");
     VFR_REQUIRE(k <= 448, VFR_EUNSUPPORTED, "vfr_topk_merge_f32: k=%d > 448", k);
+    VFR_REQUIRE((int64_t)G * k < (1ll << 31), VFR_EUNSUPPORTED, "vfr_topk_merge_f32: G*k too large");
     if (Nq == 0) return VFR_OK;
-    dim3 grid((unsigned)vfr::cdiv(Nq, 4)), block(256);
-    if (vfr::kpl_for(k) == 4)
-        hipLaunchKernelGGL((vfr::topk_merge_parts_kernel<4>), grid, block, 0, vfr::as_stream(stream), part_dist,
-                           part_idx, G, Nq, k, out_dist, out_idx);
-    else
-        hipLaunchKernelGGL((vfr::topk_merge_parts_kernel<8>), grid, block, 0, vfr::as_stream(stream), part_dist,
-                           part_idx, G, Nq, k, out_dist, out_idx);
-    VFR_CHECK_LAUNCH("topk_merge_parts_kernel");
+    return launch_merge_parts(part_dist, part_idx, false, G, Nq, k, out_dist, out_idx, nullptr, stream);
+}
+
+int vfr_topk_pack_keys(const float *dist, const int64_t *idx, int64_t n, int64_t *keys, vfr_stream_t stream)
+{
+    VFR_REQUIRE(n >= 0 && (n == 0 || (dist && idx && keys)), VFR_EINVAL, "vfr_topk_pack_keys: bad argument");
+    if (n == 0) return VFR_OK;
+    hipLaunchKernelGGL(vfr::topk_pack_keys_kernel, dim3((unsigned)vfr::cdiv(n, 256)), dim3(256), 0,
+                       vfr::as_stream(stream), dist, idx, n, keys);
+    VFR_CHECK_LAUNCH("topk_pack_keys_kernel");
+    return VFR_OK;
+}
+
+int vfr_topk_merge_keys(const int64_t *part_keys, int G, int64_t Nq, int k, float *out_dist, int64_t *out_idx,
+                        int64_t *out_keys, vfr_stream_t stream)
+{
+    VFR_REQUIRE(part_keys && G > 0 && Nq >= 0 && k > 0 && ((out_dist && out_idx) || out_keys) &&
+                (out_dist == nullptr) == (out_idx == nullptr), VFR_EINVAL, "vfr_topk_merge_keys: bad argument");
+    VFR_REQUIRE(k <= 448, VFR_EUNSUPPORTED, "vfr_topk_merge_keys: k=%d > 448", k);
+    VFR_REQUIRE((int64_t)G * k < (1ll << 31), VFR_EUNSUPPORTED, "vfr_topk_merge_keys: G*k too large");
+    if (Nq == 0) return VFR_OK;
+    return launch_merge_parts(nullptr, part_keys, true, G, Nq, k, out_dist, out_idx, out_keys, stream);
+}
+
+int vfr_gt_best_keys_f32(const float *own_scores, int64_t n_sel, int M, int score_stride, const uint8_t *labels, int R,
+                         int label_stride, const int64_t *id_base, const int64_t *sel, int64_t Nq, int64_t *keys,
+                         vfr_stream_t stream)
+{
+    VFR_REQUIRE(keys && R > 0 && Nq >= 0 && n_sel >= 0 && M >= 0 && score_stride >= M && label_stride >= M, VFR_EINVAL,
+                "vfr_gt_best_keys_f32: bad argument");
+    VFR_REQUIRE(n_sel == 0 || (own_scores && labels && id_base && sel), VFR_EINVAL, "vfr_gt_best_keys_f32: null input");
+    if (Nq == 0) return VFR_OK;
+    hipLaunchKernelGGL(vfr::gt_fill_keys_kernel, dim3((unsigned)vfr::cdiv((int64_t)R * Nq, 256)), dim3(256), 0,
+                       vfr::as_stream(stream), (int64_t)R * Nq, keys);
+    VFR_CHECK_LAUNCH("gt_fill_keys_kernel");
+    if (n_sel == 0) return VFR_OK;
+    hipLaunchKernelGGL(vfr::gt_best_keys_kernel, dim3((unsigned)vfr::cdiv(n_sel, 4)), dim3(256), 0, vfr::as_stream(stream),
+                       own_scores, n_sel, M, score_stride, labels, R, label_stride, id_base, sel, Nq, keys);
+    VFR_CHECK_LAUNCH("gt_best_keys_kernel");
     return VFR_OK;
 }
 

@@ -55,6 +55,15 @@ class HipOps:
     def topk_merge(self, part_dist, part_idx):
         return self.v.topk_merge(part_dist, part_idx)
 
+    def pack_keys(self, dist_t, idx_t, out=None):
+        return self.v.topk_pack_keys(dist_t, idx_t, out)
+
+    def merge_keys(self, part_keys, want_lists=True, want_keys=False):
+        return self.v.topk_merge_keys(part_keys, want_lists, want_keys)
+
+    def gt_best_keys(self, own_scores, labels, id_base, sel, Nq):
+        return self.v.gt_best_keys(own_scores, labels, id_base, sel, Nq)
+
 
 def shard_range(num_videos: int, rank: int, world: int):
     """Contiguous, balanced split of the video iteration order."""
@@ -243,14 +252,11 @@ def prepare_gt(shard: CorpusShard, own_global, labels) -> QueryGT:
 def best_positive_keys(shard: CorpusShard, Q, gt: QueryGT, ops, world=1):
     """Per (threshold, query): key of the best ground-truth-positive moment = min over positives of
     (score, global id).  Only the rank that owns the query's video can see it; others contribute KEY_INF."""
-    keys = torch.full((gt.num_thresholds, gt.num_queries), KEY_INF, dtype=torch.int64, device=shard.device)
     if gt.sel is not None:
         sc = ops.score_own(Q[gt.sel].contiguous(), shard.bank, gt.own_local)      # [n_sel, Mown], +inf padded
-        M = min(sc.shape[1], gt.labels.shape[2])
-        ids = gt.base[:, None] + torch.arange(M, device=shard.device)[None, :]
-        k = _pack_key(sc[:, :M].contiguous(), ids)                                # [n_sel, M]
-        k = torch.where(gt.labels[:, :, :M], k[None], torch.full_like(k, KEY_INF)[None])
-        keys[:, gt.sel] = k.min(dim=2).values
+        keys = ops.gt_best_keys(sc, gt.labels, gt.base, gt.sel, gt.num_queries)
+    else:
+        keys = torch.full((gt.num_thresholds, gt.num_queries), KEY_INF, dtype=torch.int64, device=shard.device)
     dist = _dist() if world > 1 else None
     if dist is not None:
         dist.all_reduce(keys, op=dist.ReduceOp.MIN)
@@ -266,12 +272,16 @@ def corpus_ranks(shard: CorpusShard, Q, own_global, labels, ops=None, k=0, world
     ops = ops or HipOps()
     gt = gt if gt is not None else prepare_gt(shard, own_global, labels)
     keys = best_positive_keys(shard, Q, gt, ops, world)
-    if bool((keys == KEY_INF).any()):
-        raise IndexError("index 0 is out of bounds for axis 0 with size 0 (no ground-truth-positive moment)")
+    missing = (keys == KEY_INF).any()                          # read AFTER the passes below are queued: no mid-step host sync
+
+    def check():
+        if bool(missing):
+            raise IndexError("index 0 is out of bounds for axis 0 with size 0 (no ground-truth-positive moment)")
     rank_dist, rank_idx = _unpack_key(keys)
     R = keys.shape[0]
     if R == 2:
         od, oi, counts = sharded_search(shard, Q, k, rank_dist.contiguous(), rank_idx.contiguous(), ops, world, workspace)
+        check()
         return counts, od, oi
     # any other number of thresholds (validate_epoch's 11-point PR sweep, a single threshold): pairs of rank keys,
     # the shape the fused kernel is instantiated for; an odd tail repeats its last key.  Top-k rides on the first pair.
@@ -284,6 +294,7 @@ def corpus_ranks(shard: CorpusShard, Q, own_global, labels, ops=None, k=0, world
         if r0 == 0:
             od, oi = d, i
         parts.append(c[:R - r0])
+    check()
     return torch.cat(parts), od, oi
 
 
@@ -315,34 +326,36 @@ def sharded_search(shard: CorpusShard, Q, k, rank_dist, rank_idx, ops, world=1, 
     s_r = min(nloc, max(1, -(-SAMPLE_VIDEOS // world)))
     bank_a = ops.slice_bank(shard.bank, counts_loc, 0, s_r)
     d_a, i_a, cnt = ops.score_topk(Q, bank_a, k, rank_dist, rank_idx, workspace=workspace)
-    s_d, s_i = gather_merge_topk(d_a, i_a, ops, world)                        # global sample top-k, every rank
-    seed = torch.where(s_i[:, k - 1] >= 0, _pack_key(s_d[:, k - 1].contiguous(), s_i[:, k - 1].clamp(min=0)),
-                       torch.full_like(s_i[:, k - 1], KEY_INF)).contiguous()
+    # exchange buffer: slot g < world = rank g's list, slot world = the global sample list (second exchange only)
+    buf = torch.empty((world + 1,) + tuple(d_a.shape), dtype=torch.int64, device=d_a.device)
+    slots = [buf[g] for g in range(world)]
+    dist.all_gather(slots, ops.pack_keys(d_a, i_a))
+    _, _, s_k = ops.merge_keys(buf[:world], want_lists=False, want_keys=True)   # global sample top-k, every rank
+    buf[world].copy_(s_k)
+    seed = s_k[:, k - 1].contiguous()                                           # its k-th key (KEY_INF if fewer than k)
     if s_r < nloc:
         bank_b = ops.slice_bank(shard.bank, counts_loc, s_r, nloc)
         d_b, i_b, cnt = ops.score_topk(Q, bank_b, k, rank_dist, rank_idx, workspace=workspace, count_lt=cnt, thr_seed=seed)
+        mine = ops.pack_keys(d_b, i_b)
     else:
-        d_b, i_b = torch.full_like(d_a, float("inf")), torch.full_like(i_a, -1)
+        mine = torch.full_like(s_k, KEY_INF)
     if cnt is not None:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    od, oi = gather_merge_topk(d_b, i_b, ops, world, extra=(s_d, s_i))
+    dist.all_gather(slots, mine)
+    od, oi, _ = ops.merge_keys(buf)
     return od, oi, cnt
 
 
 def gather_merge_topk(od, oi, ops, world, extra=None):
-    """Exchange step: all_gather the per-shard [Nq, k] lists (dist and ids as one packed int64 key tensor -> a
-    single collective), then merge with the (distance, id) tie-break.  ``extra`` = an additional (dist, idx) list
-    every rank already holds (the global sample top-k)."""
+    """Exchange step on its own: all_gather the per-shard [Nq, k] lists as packed int64 keys (a single collective),
+    then merge with the (distance, id) tie-break.  ``extra`` = an additional (dist, idx) list every rank holds."""
     dist = _dist()
-    packed = torch.where(oi >= 0, _pack_key(od, oi.clamp(min=0)), torch.full_like(oi, KEY_INF))
-    parts = [torch.empty_like(packed) for _ in range(world)]
-    dist.all_gather(parts, packed)
+    buf = torch.empty((world + (extra is not None),) + tuple(od.shape), dtype=torch.int64, device=od.device)
+    dist.all_gather([buf[g] for g in range(world)], ops.pack_keys(od, oi))
     if extra is not None:
-        parts.append(torch.where(extra[1] >= 0, _pack_key(extra[0], extra[1].clamp(min=0)), torch.full_like(extra[1], KEY_INF)))
-    allk = torch.stack(parts)                                             # [G (+1), Nq, k]
-    pd, pi = _unpack_key(allk)
-    pi = torch.where(allk == KEY_INF, torch.full_like(pi, -1), pi)
-    return ops.topk_merge(pd.contiguous(), pi.contiguous())
+        ops.pack_keys(extra[0], extra[1], out=buf[world])
+    d, i, _ = ops.merge_keys(buf)
+    return d, i
 
 
 class TorchCpuOps:
@@ -446,6 +459,33 @@ class TorchCpuOps:
         od = torch.where(srt == KEY_INF, torch.full_like(od, float("inf")), od)
         oi = torch.where(srt == KEY_INF, torch.full_like(oi, -1), oi)
         return od, oi
+
+    def pack_keys(self, dist_t, idx_t, out=None):
+        keys = torch.where(idx_t >= 0, _pack_key(dist_t, idx_t.clamp(min=0)), torch.full_like(idx_t, KEY_INF))
+        if out is not None:
+            out.copy_(keys)
+            return out
+        return keys
+
+    def merge_keys(self, part_keys, want_lists=True, want_keys=False):
+        G, Nq, k = part_keys.shape
+        srt = part_keys.clamp(max=KEY_INF).permute(1, 0, 2).reshape(Nq, G * k).sort(dim=1).values[:, :k].contiguous()
+        od = oi = None
+        if want_lists:
+            od, oi = _unpack_key(srt)
+            od = torch.where(srt == KEY_INF, torch.full_like(od, float("inf")), od)
+            oi = torch.where(srt == KEY_INF, torch.full_like(oi, -1), oi)
+        return od, oi, (srt if want_keys else None)
+
+    def gt_best_keys(self, own_scores, labels, id_base, sel, Nq):
+        R = labels.shape[0]
+        M = min(own_scores.shape[1], labels.shape[2])
+        ids = id_base[:, None] + torch.arange(M)[None, :]
+        k = _pack_key(own_scores[:, :M].contiguous(), ids)
+        k = torch.where(labels[:, :, :M].bool(), k[None], torch.full_like(k, KEY_INF)[None])
+        keys = torch.full((R, Nq), KEY_INF, dtype=torch.int64)
+        keys[:, sel] = k.min(dim=2).values.clamp(max=KEY_INF)
+        return keys
 
 
 def ops_for(device):
