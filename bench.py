@@ -170,9 +170,11 @@ def main():
 
     def step():
         with torch.no_grad():
-            shard = make_shard(model.encode_clips(seg, ctx, clip_off))
-            Q = engine.encode_queries(model, tokens, dev, ops, rank, world)
-            return engine.corpus_ranks(shard, Q, own, labels, ops, k=args.k, world=world, workspace=ws, gt=gt)
+            # a rank's two encoders are small enough at N > 1 to leave CUs idle in their partial tile rounds: run them side
+            # by side there; at N = 1 they stay back to back (the per-kernel durations quoted in `roofline` are then undisturbed)
+            emb, Q = engine.overlapped(dev, lambda: model.encode_clips(seg, ctx, clip_off),
+                                       lambda: engine.encode_queries(model, tokens, dev, ops, rank, world), enable=world > 1)
+            return engine.corpus_ranks(make_shard(emb), Q, own, labels, ops, k=args.k, world=world, workspace=ws, gt=gt)
 
     def barrier():
         if dist is not None:

@@ -3,7 +3,7 @@
 collectives are replaced by local stand-ins (all_gather = N copies of the own tensor, all_reduce = no-op), so
 everything except wire time is timed: sample pass, merges of N lists, seeded main pass, key packing.
 The duplicated sample keeps the seed at the same quantile as the real global sample (k/N-th best of 256/N videos).
-usage: rank_sim.py [N] [reps]"""
+usage: rank_sim.py [N] [reps] [overlap 0|1]"""
 import sys, time
 from pathlib import Path
 import numpy as np, torch
@@ -13,6 +13,7 @@ from vfr_amd import _vfr, engine, models, synth
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+OVERLAP = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 Nv_all, Nq, n, F, k = 10000, 5000, 21, 4096, 100
 dev = torch.device("cuda:0")
 
@@ -77,8 +78,13 @@ def step(split=False):
         def mark():
             if split:
                 torch.cuda.synchronize(); t.append(time.perf_counter())
-        shard = make_shard(model.encode_clips(seg, ctx, clip_off)); mark()
-        Q = engine.encode_queries(model, tokens, dev, ops, 0, N); mark()
+        if OVERLAP and not split:
+            emb, Q = engine.overlapped(dev, lambda: model.encode_clips(seg, ctx, clip_off),
+                                       lambda: engine.encode_queries(model, tokens, dev, ops, 0, N))
+            shard = make_shard(emb)
+        else:
+            shard = make_shard(model.encode_clips(seg, ctx, clip_off)); mark()
+            Q = engine.encode_queries(model, tokens, dev, ops, 0, N); mark()
         out = engine.corpus_ranks(shard, Q, own, labels, ops, k=k, world=N, workspace=ws, gt=gt); mark()
         if split:
             for name, a, b in zip(("clip", "query", "score+exchange"), t, t[1:]):

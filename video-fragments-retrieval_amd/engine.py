@@ -158,6 +158,34 @@ def encode_clips_streamed(ops, model, seg, ctx, off, device, chunk_clips=None):
     return out
 
 
+_SIDE_STREAMS = {}
+
+
+def overlapped(device, main_fn, side_fn, enable=True):
+    """Run two independent encoder passes concurrently: ``side_fn`` on a side HIP stream, ``main_fn`` on the current one.
+
+    The clip encoder and the query encoder do not depend on each other; run back to back, each leaves CUs idle in its
+    partial tile rounds (a rank's LSTM step at 8 GPUs is 576 tiles on 512 slots), run side by side the dispatcher fills
+    those with the other kernel's workgroups.  Returns (main result, side result) with the current stream ordered after
+    both.  Off (``enable`` false, or a CPU device) it is ``main_fn(), side_fn()``."""
+    dev = torch.device(device)
+    if not enable or dev.type != "cuda":
+        return main_fn(), side_fn()
+    cur = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get((dev, cur.cuda_stream))
+    if side is None:
+        side = _SIDE_STREAMS[(dev, cur.cuda_stream)] = torch.cuda.Stream(dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        b = side_fn()
+    a = main_fn()
+    cur.wait_stream(side)
+    for t in (b if isinstance(b, (tuple, list)) else (b,)):
+        if isinstance(t, torch.Tensor):
+            t.record_stream(cur)                      # allocated on the side stream, consumed on the current one
+    return a, b
+
+
 def corpus_from_embeddings(emb, counts, device, ops=None, rank=0, world=1) -> CorpusShard:
     """Same, from precomputed clip embeddings [sum n, D] of the whole corpus (per-item iterator API)."""
     ops = ops or HipOps()

@@ -45,11 +45,11 @@ def _drain_queries(lang_iterator):
     return tokens, videos, annot_ids
 
 
-def embed_corpus(model, video_iterator, device, ops, rank=0, world=1):
+def embed_corpus(model, video_iterator, device, ops, rank=0, world=1, drained=None):
     """-> (CorpusShard, video names).  Uses the dataset's packed FeatureBank (factored clip encoder, one
     launch sequence for the whole shard) when the iterator exposes one; otherwise embeds the per-video
     ``[n, 2F+2]`` tensors the iterator yields, concatenated into one batch."""
-    names, feats = _drain_videos(video_iterator)
+    names, feats = drained if drained is not None else _drain_videos(video_iterator)
     dataset = getattr(video_iterator, "dataset", None)
     if hasattr(dataset, "feature_bank"):
         return engine.build_corpus(model, dataset.feature_bank(names), device, ops, rank, world), names
@@ -59,21 +59,30 @@ def embed_corpus(model, video_iterator, device, ops, rank=0, world=1):
     return engine.corpus_from_embeddings(emb, counts, device, ops, rank, world), names
 
 
+def _encode_both(model, video_iterator, drained, tokens, device, ops, rank, world, query_fn=None):
+    """Clip shard and query batch; on a sharded run the two independent encoders run side by side (engine.overlapped)."""
+    def queries():
+        with torch.no_grad():
+            return query_fn() if query_fn else engine.encode_queries(model, torch.cat(tokens), device, ops, rank, world)
+    (shard, names), Q = engine.overlapped(device, lambda: embed_corpus(model, video_iterator, device, ops, rank, world, drained),
+                                          queries, enable=world > 1 and len(tokens) > 0)
+    return shard, names, Q
+
+
 def evaluate(model, video_iterator, lang_iterator, annotations, device, preliminary=100, model_types=['model'],
              iou_thresholds=[0.5, 0.7], rank=0, world=1, return_topk=0):
     was_training = model.training
     model.eval()
     ops = engine.ops_for(device)
-    shard, names = embed_corpus(model, video_iterator, device, ops, rank, world)
-    video_index = {name: i for i, name in enumerate(names)}
-
+    drained = _drain_videos(video_iterator)
     tokens, q_videos, annot_ids = _drain_queries(lang_iterator)
     if not tokens:
+        embed_corpus(model, video_iterator, device, ops, rank, world, drained)
         model.train(was_training)
         return {f"{mt}, IoU={thr}": get_metrics({1: [], 10: [], 100: [], "MR": []})
                 for mt, thr in itertools.product(model_types, iou_thresholds)}
-    with torch.no_grad():
-        Q = engine.encode_queries(model, torch.cat(tokens), device, ops, rank, world)
+    shard, names, Q = _encode_both(model, video_iterator, drained, tokens, device, ops, rank, world)
+    video_index = {name: i for i, name in enumerate(names)}
     own = np.asarray([video_index[v] for v in q_videos], np.int64)
     times = [annotations[a]["times"] for a in annot_ids]
     labels = engine.gt_label_table(times, shard.counts_all[own], list(iou_thresholds), strict=True)
@@ -126,17 +135,14 @@ def validate_epoch(model, video_iterator, lang_iterator, annotations, device, si
     was_training = model.training
     model.eval()
     ops = engine.ops_for(device)
-    shard, names = embed_corpus(model, video_iterator, device, ops, rank, world)
-    video_index = {name: i for i, name in enumerate(names)}
+    drained = _drain_videos(video_iterator)
     thr_range = [i / 10 for i in range(11)] if size == -1 else list(iou_thresholds)
 
     tokens, q_videos, annot_ids = _drain_queries(lang_iterator if size <= 0 else itertools.islice(lang_iterator, size))   # :186 never fires for size <= 0
     nq = len(tokens)
-    with torch.no_grad():
-        if bert:
-            Q = model(torch.cat(tokens).to(device), False, device, True).contiguous()
-        else:
-            Q = engine.encode_queries(model, torch.cat(tokens), device, ops, rank, world)
+    bert_fn = (lambda: model(torch.cat(tokens).to(device), False, device, True).contiguous()) if bert else None
+    shard, names, Q = _encode_both(model, video_iterator, drained, tokens, device, ops, rank, world, bert_fn)
+    video_index = {name: i for i, name in enumerate(names)}
     own = np.asarray([video_index[v] for v in q_videos], np.int64)
     times = [annotations[a]["times"] for a in annot_ids]
     labels = engine.gt_label_table(times, shard.counts_all[own], thr_range, strict=False)
