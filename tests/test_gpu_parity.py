@@ -311,6 +311,22 @@ def test_vgg_stack_bit_exact_reduced_width(vfr, oracle, hw):
     assert same(got, want)
 
 
+# layer shapes that reach every conv launch form of gemm_nt: 128x64 tiles (Cout <= 64), 64-row tiles (< 384 workgroups),
+# the XCD-aware tile order (several column tiles, >= 64 row tiles) and the plain 128x128 grid
+WIDE_VGG = [8, 520, "M", 136, 72, "M", 8, "M", 8, "M", 8, "M"]
+TALL_VGG = [72, "M", 8, "M", 8, "M", 8, "M", 8, "M"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,T", [(WIDE_VGG, 5), (TALL_VGG, 17)])
+def test_vgg_conv_launch_forms_bit_exact(vfr, oracle, cfg, T):
+    frames = synth.frames_u8(T, 64, 48, seed=4)
+    cw, cb, fc6, fc7 = synth.vgg_weights(cfg, (64, 48), 64, seed=4)
+    got = vfr.vgg_fc7(dev(frames), cfg, [dev(w) for w in cw], [dev(b) for b in cb],
+                      (dev(fc6[0]), dev(fc6[1])), (dev(fc7[0]), dev(fc7[1])))
+    assert same(got, oracle.vgg_fc7(frames, cw, cb, fc6, fc7, cfg))
+
+
 # ---------------------------------------------------------------------------------------------
 def test_full_size_properties(vfr):
     """BASELINE config 1 shape (10k videos x 21 clips) where the oracle is too slow: size-independent

@@ -146,25 +146,30 @@ __device__ unsigned long long g_gemm_stamps[4];
 // in its (tiny) load blocks and 25 % at the barriers -- the load block of one group crawls beside the other group's MFMA
 // block (raising that block's wave priority with s_setprio changes nothing).  Kept as a switchable variant for the next round's
 // work on that stall.
-template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false>
+// NARROW = 64-column workgroup tile, the four waves stacked along M (each wave still 16*TI x 64): for operands with N <= 64
+// (VGG conv1_1 / conv1_2), where the 128-column tile would spend half of every MFMA on columns that do not exist.
+template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false, bool NARROW = false>
 __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
-    constexpr int TBM = 64 * MI, NA = 2 * MI;           // tile rows; float4 staging loads of A per thread (W: 4)
+    static_assert(!NARROW || (MI == 1 && !LSTM && !PP), "narrow tile: 128 x 64 only");
+    constexpr int TBM = NARROW ? 128 * MI : 64 * MI;    // tile rows
+    constexpr int BN = NARROW ? 64 : MBN;               // tile columns
+    constexpr int NA = TBM / 32, NW = BN / 32;          // float4 staging loads per thread of A / of W
     // double-buffered tiles: [2][A TBMx36 | W 128x36] floats (73,728 B at MI = 2) -> two workgroups per CU
     constexpr int NBUF = PP ? 1 : (LSTM ? VFR_LSTM_NBUF : VFR_GEMM_NBUF);
-    __shared__ __attribute__((aligned(16))) float lds_all[(PP ? 2 : 1) * NBUF * (TBM + MBN) * MLD];
+    __shared__ __attribute__((aligned(16))) float lds_all[(PP ? 2 : 1) * NBUF * (TBM + BN) * MLD];
     const int grp = PP ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // tile group of this wave
-    float *lds = lds_all + grp * NBUF * (TBM + MBN) * MLD;
+    float *lds = lds_all + grp * NBUF * (TBM + BN) * MLD;
     const int tid = PP ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NARROW ? wave : wave >> 1, wn = NARROW ? 0 : wave & 1;
     int64_t m0 = (int64_t)(PP ? blockIdx.x * 2 + grp : blockIdx.x) * TBM;
-    int n0 = blockIdx.y * MBN;
+    int n0 = blockIdx.y * BN;
     bool active = true;                                  // PP: a group without a tile still takes part in the barriers
     if (!LSTM && g.xcd_cols > 0) {
         const unsigned L = blockIdx.x, per = 8u * (unsigned)g.xcd_cols, within = L % per;
         const int64_t rt = (int64_t)(L / per) * 8 + (within & 7u);
         m0 = (PP ? rt * 2 + grp : rt) * TBM;
-        n0 = (int)(within >> 3) * MBN;
+        n0 = (int)(within >> 3) * BN;
         if (m0 >= g.M) { if (!PP) return; active = false; }     // grid padded to whole groups of 8 row tiles
     }
     if (PP && !LSTM && m0 >= g.M) active = false;
@@ -215,7 +220,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         }
     };
 
-    float4 ra[NA], rw[4];
+    float4 ra[NA], rw[NW];
     // Zero-fill of staged elements outside the operand (conv padding taps, the tail of a segmented K) is decided when the
     // load is ISSUED but applied when the registers are written to LDS: a select right after the load would make hipcc
     // wait for the load (vmcnt(0)) before the MFMA block and expose its latency in every K-tile.
@@ -225,9 +230,9 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // Staging loads.  Full K-tiles use UNCONDITIONAL loads (row index clamped into range; rows past M / N are
     // never stored) so the compiler can leave them in flight across the MFMA block -- a per-load bounds branch
     // makes hipcc drain vmcnt(0) right after issuing them.  Only the last, partial K-tile takes the guarded form.
-    const float *arow[NA], *wrow[4], *arow2[NA], *wrow2[4];
+    const float *arow[NA], *wrow[NW], *arow2[NA], *wrow2[NW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NW; ++i) {
         const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
         int64_t nw = (int64_t)n0 + row < g.N ? (int64_t)n0 + row : g.N - 1;
         if (LSTM) {   // tile column c = (wn, tj, l15): gate = tj = (c >> 4) & 3, unit = 32*blockIdx.y + 16*wn + (c & 15)
@@ -256,16 +261,20 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             else     ra[i] = make_float4(arow[i][k0], arow[i][k0 + 1], arow[i][k0 + 2], arow[i][k0 + 3]);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NW; ++i) {
             if (VEC) rw[i] = *reinterpret_cast<const float4 *>(wrow[i] + k0);
             else     rw[i] = make_float4(wrow[i][k0], wrow[i][k0 + 1], wrow[i][k0 + 2], wrow[i][k0 + 3]);
         }
     };
     auto gload_tail = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
-            if (i < NA) ra[i] = load4_guard<false>(g.A, g.lda, m0 + row, g.M, k0 + kk, g.K);
+            ra[i] = load4_guard<false>(g.A, g.lda, m0 + row, g.M, k0 + kk, g.K);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
             rw[i] = load4_guard<false>(g.W, g.ldw, (int64_t)n0 + row, g.N, k0 + kk, g.K);
         }
     };
@@ -301,7 +310,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             za[i] = !ok;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rw[i] = *reinterpret_cast<const float4 *>(wrow[i] - kk + kc);     // row clamped, k clamped
+        for (int i = 0; i < NW; ++i) rw[i] = *reinterpret_cast<const float4 *>(wrow[i] - kk + kc);    // row clamped, k clamped
         zw = !kok;
     };
     // ---- segmented-K loader (LSTM step): tiles [0, nk1) walk [A | W] over K, tiles [nk1, nk1+nk2) walk [A2 | W2]
@@ -320,7 +329,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             za[i] = !kok;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NW; ++i) {
             const float *wp = (second ? wrow2[i] : wrow[i]) - kk + kc;
             rw[i] = *reinterpret_cast<const float4 *>(wp);
         }
@@ -329,7 +338,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     const int nk_full = LSTM ? nk1 + (g.K2 + MBK - 1) / MBK
                              : CONV ? (g.K + MBK - 1) / MBK : g.K / MBK;     // conv / lstm: every tile through a select loader
     auto swrite = [&](int b) {
-        float *As = lds + b * (TBM + MBN) * MLD, *Ws = As + TBM * MLD;
+        float *As = lds + b * (TBM + BN) * MLD, *Ws = As + TBM * MLD;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
@@ -338,7 +347,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             *reinterpret_cast<float4 *>(&As[row * MLD + kk]) = v;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NW; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
             float4 v = rw[i];
             if (CONV || LSTM) { v.x = zw ? 0.f : v.x; v.y = zw ? 0.f : v.y; v.z = zw ? 0.f : v.z; v.w = zw ? 0.f : v.w; }
@@ -346,7 +355,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         }
     };
     auto compute = [&](int b) {
-        const float *As = lds + b * (TBM + MBN) * MLD, *Ws = As + TBM * MLD;
+        const float *As = lds + b * (TBM + BN) * MLD, *Ws = As + TBM * MLD;
         // fragment of tile row block ti at k-slice k4: ONE dword per lane, A[16*ti + (lane & 15)][4*k4 + (lane >> 4)] -- exactly
         // the 16x16x4 operand layout, read with ds_read_b32 (bank = 36*r + q mod 64: 64 distinct banks, conflict-free)
         const float *ap = &As[(wm * (16 * TI) + l15) * MLD + lq];
@@ -418,7 +427,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         const int nk = nk_full;
         float fa[RING][TI], fb[RING][4];
         auto frag_read = [&](int buf, int slice, int slot) {
-            const float *As = lds + buf * (TBM + MBN) * MLD, *Ws = As + TBM * MLD;
+            const float *As = lds + buf * (TBM + BN) * MLD, *Ws = As + TBM * MLD;
             const float *ap = &As[(wm * (16 * TI) + l15) * MLD + lq + slice * 4];
             const float *wp = &Ws[(wn * 64 + l15) * MLD + lq + slice * 4];
 #pragma unroll
@@ -597,7 +606,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp)
     gemm_nt_mfma_body<VEC, false>(g);         // kernarg array there (an s_load + lgkmcnt(0) would also drain the LDS reads)
 }
 
-__global__ __launch_bounds__(256, 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true>(g); }
+template <int MI = 2, bool NARROW = false>
+__global__ __launch_bounds__(256, 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true, false, MI, false, NARROW>(g); }
 
 template <int MI>
 __global__ __launch_bounds__(256, VFR_LSTM_WAVES) void lstm_step_mfma_pair(GemmPair gp)
@@ -729,12 +739,16 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
         VFR_REQUIRE((g.conv_cin & 3) == 0 && g.K == 9 * g.conv_cin && (g.ldw & 3) == 0 &&
                         ((((uintptr_t)g.A) | ((uintptr_t)g.W)) & 15) == 0,
                     VFR_EINVAL, "gemm_nt(conv): needs Cin %% 4 == 0, K = 9*Cin and 16-byte aligned operands");
-        if (grid.y > 1 && grid.y <= 16 && grid.x >= 64) {     // XCD-aware tile order (see xcd_cols): activations stream once
+        if (g.N <= 64) {                                      // conv1_x: 128 x 64 tiles, no MFMA spent on absent columns
+            hipLaunchKernelGGL((conv3x3_nhwc_mfma<1, true>), dim3(grid.x, 1), dim3(256), 0, st, g);
+        } else if ((int64_t)grid.x * grid.y < 384) {          // under 1.5 workgroups per CU: 64-row tiles (as the dense GEMM)
+            hipLaunchKernelGGL((conv3x3_nhwc_mfma<1, false>), dim3((unsigned)cdiv(g.M, 64), grid.y), dim3(256), 0, st, g);
+        } else if (grid.y > 1 && grid.y <= 16 && grid.x >= 64) {     // XCD-aware tile order (see xcd_cols): activations stream once
             GemmArgs gx = g;
             gx.xcd_cols = (int)grid.y;
-            hipLaunchKernelGGL(conv3x3_nhwc_mfma, dim3((unsigned)(cdiv(grid.x, 8) * 8 * grid.y)), dim3(256), 0, st, gx);
+            hipLaunchKernelGGL((conv3x3_nhwc_mfma<2, false>), dim3((unsigned)(cdiv(grid.x, 8) * 8 * grid.y)), dim3(256), 0, st, gx);
         } else {
-            hipLaunchKernelGGL(conv3x3_nhwc_mfma, grid, dim3(256), 0, st, g);
+            hipLaunchKernelGGL((conv3x3_nhwc_mfma<2, false>), grid, dim3(256), 0, st, g);
         }
         VFR_CHECK_LAUNCH("conv3x3_nhwc_mfma");
         return VFR_OK;

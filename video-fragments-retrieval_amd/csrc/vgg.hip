@@ -191,7 +191,17 @@ static int run_avgpool(const float *x, int64_t planes, int H, int W, float *y, h
     return VFR_OK;
 }
 
-constexpr int VGG_FRAME_CHUNK = 32;   // frames per pass through the conv stack (bounds the workspace)
+// Frames per pass through the conv stack.  The late layers are small GEMMs per frame (conv5: 196 rows x 512): at 32 frames
+// they fill less than one round of the chip's 512 workgroup slots, at 150 (one DiDeMo video, get_rgb_features.py:47-61) a
+// round is ~90 % full.  The two ping-pong activation buffers cost 2 x 12.8 MB per frame -- 3.9 GB at 150, nothing of 288 GB.
+// T frames are split into equal chunks of at most VGG_FRAME_CHUNK.
+constexpr int VGG_FRAME_CHUNK = 160;
+static int vgg_chunk(int T)
+{
+    if (T <= VGG_FRAME_CHUNK) return T;
+    const int n = (T + VGG_FRAME_CHUNK - 1) / VGG_FRAME_CHUNK;
+    return (T + n - 1) / n;
+}
 
 struct VggPlan { size_t act_elems, wr_elems; int c_last, h_last, w_last; bool ok; };
 static VggPlan plan_vgg(int chunk, int H, int W, const int *cfg, int ncfg)
@@ -256,7 +266,7 @@ int vfr_adaptive_avgpool7_f32(const float *x, int B, int C, int H, int W, float 
 size_t vfr_vgg_fc7_workspace_bytes(int T, int H, int W, const int *cfg_host, int ncfg, int fc_dim)
 {
     if (T < 0 || H <= 0 || W <= 0 || !cfg_host || ncfg <= 0 || fc_dim <= 0) return 0;
-    int chunk = T < vfr::VGG_FRAME_CHUNK ? T : vfr::VGG_FRAME_CHUNK;
+    const int chunk = vfr::vgg_chunk(T);
     vfr::VggPlan p = vfr::plan_vgg(chunk, H, W, cfg_host, ncfg);
     size_t act = vfr::align_up(p.act_elems * sizeof(float), 256);
     size_t pooled = vfr::align_up((size_t)T * p.c_last * 49 * sizeof(float), 256);
@@ -274,7 +284,7 @@ int vfr_vgg_fc7_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *
                     T >= 0 && H > 0 && W > 0 && ncfg > 0 && fc_dim > 0,
                 VFR_EINVAL, "vfr_vgg_fc7_f32: bad argument");
     if (T == 0) return VFR_OK;
-    const int chunk = T < vfr::VGG_FRAME_CHUNK ? T : vfr::VGG_FRAME_CHUNK;
+    const int chunk = vfr::vgg_chunk(T);
     vfr::VggPlan p = vfr::plan_vgg(chunk, H, W, cfg_host, ncfg);
     VFR_REQUIRE(p.ok, VFR_EUNSUPPORTED,
                 "vfr_vgg_fc7_f32: needs conv widths that are multiples of 4 and %dx%d frames large enough for the pooling stages",
