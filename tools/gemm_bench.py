@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the chain GEMM (vfr_linear_f32) at the hot shapes.  usage: gemm_bench.py [reps]"""
+"""Time the chain GEMM (vfr_linear_f32) at the hot shapes.  usage: gemm_bench.py [reps] [other libvfr build, for A/B timing]"""
 import sys
 import time
 from pathlib import Path
@@ -12,6 +12,8 @@ from vfr_amd import _vfr
 
 dev = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+if len(sys.argv) > 2:
+    _vfr.LIB_PATH = Path(sys.argv[2]).resolve()
 torch.manual_seed(0)
 for name, M, K, N in (("lstm_rec  [5000x1000]x[4000x1000]^T", 5000, 1000, 4000), ("lstm step shape [5120x1152]x[4096x1152]^T", 5120, 1152, 4096),
                       ("2x rows  [10240x1152]x[4096x1152]^T", 10240, 1152, 4096), ("long K [5120x4096]x[4096x4096]^T", 5120, 4096, 4096), ("vis_seg  [210000x4096]x[500x4096]^T", 210000, 4096, 500),

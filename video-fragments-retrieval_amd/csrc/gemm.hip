@@ -339,6 +339,13 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                              : CONV ? (g.K + MBK - 1) / MBK : g.K / MBK;     // conv / lstm: every tile through a select loader
     auto swrite = [&](int b) {
         float *As = lds + b * (TBM + BN) * MLD, *Ws = As + TBM * MLD;
+#ifdef VFR_GEMM_NOSWRITE      /* TIMING EXPERIMENT ONLY (wrong results): staged registers are consumed but never written to LDS */
+#pragma unroll
+        for (int i = 0; i < NA; ++i) asm volatile("" :: "v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w));
+#pragma unroll
+        for (int i = 0; i < NW; ++i) asm volatile("" :: "v"(rw[i].x), "v"(rw[i].y), "v"(rw[i].z), "v"(rw[i].w));
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;

@@ -975,24 +975,31 @@ __global__ __launch_bounds__(256) void gt_best_keys_kernel(const float *__restri
     }
 }
 
-// each query against its own video (evaluate_single.py:48-53): V is per-lane here, plain loads
-__global__ __launch_bounds__(64) void score_own_kernel(const float *__restrict__ Q, int64_t Nq,
-                                                       const float *__restrict__ V,
-                                                       const int32_t *__restrict__ clip_off,
-                                                       const int32_t *__restrict__ own, int D, float eps, int Mmax,
-                                                       float *__restrict__ scores)
+// each query against its own video (evaluate_single.py:48-53).  One WAVE per query: lane c runs clip c's k-ascending
+// distance chain (the clips of a video are independent chains), the distances go through LDS, then lane s walks the spans
+// (s, s), (s, s+1), ... keeping the left-to-right running sum of the oracle.  (Thread-per-query left the chip to 79 waves
+// of 21 serial chains each: 0.27 ms for 5000 queries; this is ~15 us.)
+__global__ __launch_bounds__(256) void score_own_kernel(const float *__restrict__ Q, int64_t Nq,
+                                                        const float *__restrict__ V,
+                                                        const int32_t *__restrict__ clip_off,
+                                                        const int32_t *__restrict__ own, int D, float eps, int Mmax,
+                                                        float *__restrict__ scores)
 {
-    extern __shared__ __attribute__((aligned(16))) float ds[];
-    const int lane = threadIdx.x;
-    const int64_t q = (int64_t)blockIdx.x * 64 + lane;
+    __shared__ float ds_all[4][NMAX_DENSE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wv;
     if (q >= Nq) return;
+    float *ds = ds_all[wv];
     const int v = own[q], c0 = clip_off[v], n = clip_off[v + 1] - c0;
-    for (int m = n * (n + 1) / 2; m < Mmax; ++m) scores[q * Mmax + m] = __builtin_inff();   // slots past this video's moments
+    float *out = scores + q * Mmax;
+    for (int m = n * (n + 1) / 2 + lane; m < Mmax; m += 64) out[m] = __builtin_inff();     // slots past this video's moments
     const bool vec = (D & 3) == 0 && ((((uintptr_t)V) | ((uintptr_t)Q)) & 15) == 0;
-    for (int c = 0; c < n; ++c) {
+    const float *qr = Q + q * D;
+    for (int c = lane; c < n; c += 64) {
         float acc = 0.0f;
-        const float *vr = V + (int64_t)(c0 + c) * D, *qr = Q + q * D;
+        const float *vr = V + (int64_t)(c0 + c) * D;
         if (vec) {                                       // same k-ascending chain, 16-byte loads
+#pragma unroll 5
             for (int k = 0; k < D; k += 4) {
                 const float4 a = *reinterpret_cast<const float4 *>(vr + k), b = *reinterpret_cast<const float4 *>(qr + k);
                 float d = (a.x - b.x) + eps; acc = __builtin_fmaf(d, d, acc);
@@ -1006,14 +1013,16 @@ __global__ __launch_bounds__(64) void score_own_kernel(const float *__restrict__
                 acc = __builtin_fmaf(d, d, acc);
             }
         }
-        ds[c * 64 + lane] = __builtin_sqrtf(acc);
+        ds[c] = __builtin_sqrtf(acc);
     }
-    for (int s = 0; s < n; ++s) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    for (int s = lane; s < n; s += 64) {
         float sum = 0.0f;
         for (int e = s; e < n; ++e) {
-            const float de = ds[e * 64 + lane];
+            const float de = ds[e];
             sum = e == s ? de : sum + de;
-            scores[q * Mmax + moment_index(n, s, e)] = sum / (float)(e - s + 1);
+            out[moment_index(n, s, e)] = sum / (float)(e - s + 1);
         }
     }
 }
@@ -1151,9 +1160,8 @@ int vfr_score_own_f32(const float *Q, int64_t Nq, const float *V, const int32_t 
                 "vfr_score_own_f32: max_clips=%d (limit %d) needs Mmax >= %d, got %d", max_clips, vfr::NMAX_DENSE,
                 max_clips * (max_clips + 1) / 2, Mmax);
     if (Nq == 0) return VFR_OK;
-    hipLaunchKernelGGL(vfr::score_own_kernel, dim3((unsigned)vfr::cdiv(Nq, 64)), dim3(64),
-                       (size_t)max_clips * 64 * sizeof(float), vfr::as_stream(stream), Q, Nq, V, clip_offsets, own, D,
-                       eps, Mmax, scores);
+    hipLaunchKernelGGL(vfr::score_own_kernel, dim3((unsigned)vfr::cdiv(Nq, 4)), dim3(256), 0, vfr::as_stream(stream), Q, Nq,
+                       V, clip_offsets, own, D, eps, Mmax, scores);
     VFR_CHECK_LAUNCH("score_own_kernel");
     return VFR_OK;
 }
