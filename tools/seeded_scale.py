@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Seeded main pass of the sharded search vs shard size: T(Nv) for 5000 queries, top-100 + 2 rank keys, thr_seed = k-th
-key of a 256-video global sample (what a rank runs at N GPUs).  Shows the fixed cost per pass.  usage: seeded_scale.py"""
+key of a 256-video global sample (what a rank runs at N GPUs).  Shows the fixed cost per pass.  usage: seeded_scale.py [score_tasks values, comma separated]"""
 import sys, time
 from pathlib import Path
 import numpy as np, torch
@@ -32,7 +32,9 @@ def timed(fn, reps=10):
     return (time.perf_counter() - t) / reps * 1e3
 
 
-for Nv in (32, 128, 312, 625, 1218, 2468, 4968, 9744):
+TASKS = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]
+for Nv, tasks in [(nv, t) for nv in (312, 625, 1218, 2468, 4968, 9744) for t in TASKS]:
+    _vfr.set_option("score_tasks", tasks)
     b = _vfr.slice_bank(full, counts_all, 256, 256 + Nv)
     _vfr.set_option("profile", 1); _vfr.profile_read(reset=True)
     t_seed = timed(lambda: _vfr.score_topk(Q, b, k, rd, ri, workspace=ws, thr_seed=seed))
@@ -40,4 +42,4 @@ for Nv in (32, 128, 312, 625, 1218, 2468, 4968, 9744):
     t_un = timed(lambda: _vfr.score_topk(Q, b, k, rd, ri, workspace=ws))
     t_rank = timed(lambda: _vfr.score_topk(Q, b, 0, rd, ri, workspace=ws))
     detail = "  ".join(f"{nm} {ms / 11:.3f}x{c // 11}" for nm, (ms, c) in sites.items())
-    print(f"Nv={Nv:5d}  seeded {t_seed:7.3f} ms ({t_seed / Nv * 1e3:6.2f} us/video)  unseeded {t_un:7.3f}  rank-only {t_rank:7.3f}   [{detail}]", flush=True)
+    print(f"tasks={tasks:5d} Nv={Nv:5d}  seeded {t_seed:7.3f} ms ({t_seed / Nv * 1e3:6.2f} us/video)  unseeded {t_un:7.3f}  rank-only {t_rank:7.3f}   [{detail}]", flush=True)

@@ -1030,8 +1030,12 @@ __global__ __launch_bounds__(256) void score_own_kernel(const float *__restrict_
 static void plan_tasks(int64_t Nq, int Nv, int *groups, int *chunks)
 {
     int g = (int)cdiv(Nq, 64);
-    // 2048 wave slots at 2 waves/SIMD: aim for ~4 full rounds so the tail round stays small
-    int64_t want = cdiv(8192, g);
+    // Wave-tasks = query groups x video chunks.  More tasks even out the tail round of the 2048 wave slots, fewer tasks
+    // amortise a task's fixed cost (100 query registers, candidate flush) over more videos: the measured optimum
+    // (tools/seeded_scale.py, 5000 queries) follows ~174 * sqrt(Nv): 3k tasks at 312 videos, 6k at 1218, 16k at 9744.
+    int64_t total = opt_score_tasks() > 0 ? opt_score_tasks() : (int64_t)(174.0 * __builtin_sqrt((double)(Nv > 1 ? Nv : 1)));
+    if (opt_score_tasks() <= 0) total = total < 2048 ? 2048 : (total > 16384 ? 16384 : total);
+    int64_t want = cdiv(total, g);
     int c = (int)(want < 1 ? 1 : want);
     if (c > Nv) c = Nv < 1 ? 1 : Nv;
     if (c > 1024) c = 1024;
