@@ -184,7 +184,7 @@ def main():
     for _ in range(args.warmup):
         out = step()
     barrier()
-    _vfr.set_option("profile", 1)
+    _vfr.set_option("profile", 0 if os.environ.get("VFR_BENCH_NO_SITES") else 1)   # rehearsal switch: cost of the site events
     _vfr.profile_read(reset=True)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -244,6 +244,11 @@ def main():
     rev_rows = sum(1 + int((qlen > T_ - 1 - s).sum()) for s in range(T_)) / T_
     cfg = dict(Bq=Bq, C=C_loc, Nv=hi - lo, H=model.hidden_size, E=100, F=F, hid=500, D=100,
                n=int(round(n_eff)), Nq=Nq, T=T_, lstm_rows_per_step=(Bq + 1) + rev_rows)
+    if not sites:                                  # VFR_BENCH_NO_SITES rehearsal: nothing to attribute
+        print(json.dumps({"ms_per_step": ms_step, "value": value, "n_gpus": world, "note": "site events off (rehearsal)"}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     kernels, dom, dom_ms = {}, None, -1.0
     for name, (ms, cnt) in sites.items():
         fl = site_work(name, cfg)

@@ -159,6 +159,7 @@ def encode_clips_streamed(ops, model, seg, ctx, off, device, chunk_clips=None):
 
 
 _SIDE_STREAMS = {}
+_TLS = __import__("threading").local()          # per-thread pinned flag words (one per device)
 
 
 def overlapped(device, main_fn, side_fn, enable=True):
@@ -300,10 +301,24 @@ def corpus_ranks(shard: CorpusShard, Q, own_global, labels, ops=None, k=0, world
     ops = ops or HipOps()
     gt = gt if gt is not None else prepare_gt(shard, own_global, labels)
     keys = best_positive_keys(shard, Q, gt, ops, world)
-    missing = (keys == KEY_INF).any()                          # read AFTER the passes below are queued: no mid-step host sync
+    # "no positive moment" is known as soon as the keys are: its flag travels to pinned host memory right behind them and is
+    # read AFTER the passes below are queued, waiting only for that copy -- the host is never held until the scoring ends, so
+    # it can already queue the next batch's encoders
+    missing = (keys == KEY_INF).any()
+    async_check = keys.is_cuda
+    if async_check:
+        flags = _TLS.__dict__.setdefault("flags", {})
+        flag = flags.get(keys.device)
+        if flag is None:
+            flag = flags[keys.device] = torch.empty((), dtype=torch.bool).pin_memory()
+        flag.copy_(missing, non_blocking=True)
+        landed = torch.cuda.Event()
+        landed.record()
 
     def check():
-        if bool(missing):
+        if async_check:
+            landed.synchronize()
+        if bool(flag if async_check else missing):
             raise IndexError("index 0 is out of bounds for axis 0 with size 0 (no ground-truth-positive moment)")
     rank_dist, rank_idx = _unpack_key(keys)
     R = keys.shape[0]
