@@ -146,8 +146,8 @@ def main():
     seg = raw / (raw.norm(dim=1, keepdim=True) + 1e-5)
     clip_off = torch.from_numpy((off_all[lo:hi + 1] - off_all[lo]).astype(np.int32)).to(dev)
     nloc = (clip_off[1:] - clip_off[:-1]).long()
-    vid = torch.repeat_interleave(torch.arange(hi - lo, device=dev), nloc)
-    ctx = torch.zeros((hi - lo, F), device=dev).index_add_(0, vid, raw) / nloc[:, None].float()
+    # per-video mean of the raw rows, deterministic (index_add_ would sum with atomics: run-to-run different bits)
+    ctx = torch.segment_reduce(raw, "sum", lengths=nloc, axis=0) / nloc[:, None].float()
     ctx = ctx / (ctx.norm(dim=1, keepdim=True) + 1e-5)
     del raw
     tokens = torch.from_numpy(synth.query_tokens(Nq, seed=123)).to(dev)
@@ -277,6 +277,7 @@ def main():
                    "videos": Nv, "clips": args.clips, "queries": Nq, "k": args.k, "parallelism": f"shard{world}"},
         "gpu_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
         "median_rank_check": float(ranks[0].float().median()),
+        "ranks_checksum": int(ranks.sum()), "topk_checksum": int(out[2].sum()) if out[2] is not None else None,
         "roofline": roofline, "kernels": kernels,
     }
     if host_feed is not None:

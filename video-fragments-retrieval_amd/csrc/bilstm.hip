@@ -271,7 +271,11 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
             for (int d = 0; d < 2; ++d) {
                 const int t = d ? T - 1 - step : step;
                 g[d].A = w.X + (size_t)t * E; g[d].lda = (int64_t)T * E; g[d].W = Wih[d]; g[d].ldw = E; g[d].K = E;
-                g[d].A2 = hin + (size_t)d * H; g[d].lda2 = 2 * H; g[d].W2 = Whh[d]; g[d].ldw2 = H; g[d].K2 = H;
+                g[d].A2 = hin + (size_t)d * H; g[d].lda2 = 2 * H; g[d].W2 = Whh[d]; g[d].ldw2 = H;
+                // h_0 = 0 (models.py:50-52): every recurrent term of the first step is fma(0, w, acc) == acc for finite
+                // weights, so the chain is left where the x segment (or the projection table) put it and the step is its
+                // gather + gate epilogue only.  (A non-finite W_hh would give NaN in the reference here; not reproduced.)
+                g[d].K2 = (step == 0 && vfr::opt_lstm_skip0()) ? 0 : H;
                 g[d].bias = bih[d]; g[d].bias2 = bhh[d]; g[d].M = R; g[d].N = G;
                 g[d].lstm_c = cout + (size_t)d * R * H; g[d].lstm_cin = cin + (size_t)d * R * H;
                 g[d].lstm_h = hout + (size_t)d * H; g[d].lstm_ldh = 2 * H;
