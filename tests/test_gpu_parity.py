@@ -440,7 +440,7 @@ def test_file_dataset_pools_on_gpu_and_evaluates(vfr, oracle, golden, mode, tmp_
 
 @pytest.mark.gpu
 def test_bilstm_tile_shapes_agree(vfr, oracle):
-    """The fused LSTM step picks 64- or 128-row tiles by grid size; both are the same chains.  Forced either way on one
+    """The fused LSTM step picks 32-, 64- or 128-row tiles by batch size; all are the same chains.  Forced either way on one
     batch: identical bits to each other and (on the rows the oracle is run for) to the oracle."""
     sd = synth.model_weights(4096, seed=7)
     tokens = synth.query_tokens(1500, seed=7)
@@ -448,12 +448,12 @@ def test_bilstm_tile_shapes_agree(vfr, oracle):
             dev(sd["lang_fc.weight"]), dev(sd["lang_fc.bias"]))
     outs = {}
     try:
-        for mode in (1, 2):
+        for mode in (1, 2, 3):
             vfr.set_option("lstm_tile", mode)
             outs[mode] = vfr.bilstm_final(*args)
     finally:
         vfr.set_option("lstm_tile", 0)
-    assert torch.equal(outs[1], outs[2])
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])
     want = oracle.bilstm_final(tokens[:64], sd["word_embedding.weight"], lstm_of(sd), sd["lang_fc.weight"], sd["lang_fc.bias"])
     assert same(outs[2][:64], want)
     # the first step skips its recurrent segment (h_0 = 0 -> every term is fma(0, w, acc) == acc): same bits as running it

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Query encoder time with the fused LSTM step forced to 64- or 128-row tiles (GPU box).  usage: lstm_tile_sweep.py [B ...]"""
+"""Query encoder time with the fused LSTM step forced to 64- (1), 128- (2) or 32-row (3) tiles (GPU box).  usage: lstm_tile_sweep.py [B ...]"""
 import sys, time
 from pathlib import Path
 import torch
@@ -13,12 +13,14 @@ model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
 model = model.to(dev).eval()
 for B in [int(x) for x in sys.argv[1:]] or [5000, 2500, 1250, 625]:
     tokens = torch.from_numpy(synth.query_tokens(B, seed=123)).to(dev)
-    for mode in (0, 1, 2):
+    ref = None
+    for mode in (1, 2, 3):
         _vfr.set_option("lstm_tile", mode)
         with torch.no_grad():
             q = model.encode_queries(tokens); torch.cuda.synchronize()
             t = time.perf_counter()
             for _ in range(3): q = model.encode_queries(tokens)
             torch.cuda.synchronize()
-        print(f"B={B:5d} lstm_tile={mode}: {(time.perf_counter() - t) / 3 * 1e3:8.3f} ms", flush=True)
+        ref = q if ref is None else ref
+        print(f"B={B:5d} lstm_tile={mode}: {(time.perf_counter() - t) / 3 * 1e3:8.3f} ms  same bits as tile 1: {torch.equal(q, ref)}", flush=True)
 _vfr.set_option("lstm_tile", 0)

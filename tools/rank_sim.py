@@ -3,7 +3,7 @@
 collectives are replaced by local stand-ins (all_gather = N copies of the own tensor, all_reduce = no-op), so
 everything except wire time is timed: sample pass, merges of N lists, seeded main pass, key packing.
 The duplicated sample keeps the seed at the same quantile as the real global sample (k/N-th best of 256/N videos).
-usage: rank_sim.py [N] [reps] [overlap 0|1]"""
+usage: rank_sim.py [N] [reps] [overlap 0|1] [lstm_tile]"""
 import sys, time
 from pathlib import Path
 import numpy as np, torch
@@ -14,6 +14,8 @@ from vfr_amd import _vfr, engine, models, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 OVERLAP = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+if len(sys.argv) > 4:
+    _vfr.set_option("lstm_tile", int(sys.argv[4]))
 Nv_all, Nq, n, F, k = 10000, 5000, 21, 4096, 100
 dev = torch.device("cuda:0")
 

@@ -152,7 +152,7 @@ template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false, b
 __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
     static_assert(!NARROW || (MI == 1 && !LSTM && !PP), "narrow tile: 128 x 64 only");
-    constexpr int TBM = NARROW ? 128 * MI : 64 * MI;    // tile rows
+    constexpr int TBM = NARROW ? 128 * MI : (MI ? 64 * MI : 32);    // tile rows (MI = 0: the 32-row tile, one row tile per wave)
     constexpr int BN = NARROW ? 64 : MBN;               // tile columns
     constexpr int NA = TBM / 32, NW = BN / 32;          // float4 staging loads per thread of A / of W
     // double-buffered tiles: [2][A TBMx36 | W 128x36] floats (73,728 B at MI = 2) -> two workgroups per CU
@@ -184,7 +184,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #endif
     // accumulators: the wave's 16*TI x 64 outputs as TI x 4 tiles of v_mfma_f32_16x16x4_f32 (4 registers each); lane l holds
     // rows 4*(l>>4) + r (r = 0..3) and column l & 15 of a tile
-    constexpr int TI = 2 * MI;
+    constexpr int TI = MI ? 2 * MI : 1;
     const int l15 = lane & 15, lq = lane >> 4;
     f32x4 acc[TI][4];
     auto init_acc = [&]() {
@@ -617,7 +617,7 @@ template <int MI = 2, bool NARROW = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true, false, MI, false, NARROW>(g); }
 
 template <int MI>
-__global__ __launch_bounds__(256, VFR_LSTM_WAVES) void lstm_step_mfma_pair(GemmPair gp)
+__global__ __launch_bounds__(256, MI ? VFR_LSTM_WAVES : 3) void lstm_step_mfma_pair(GemmPair gp)
 {
     const GemmArgs g = gp.p[blockIdx.z];      // private copy, see gemm_nt_mfma_pair
     gemm_nt_mfma_body<true, false, true, MI>(g);
@@ -692,8 +692,15 @@ int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
     GemmPair gp{{g0, g1}};
     // 64-row tiles by default: a step is only a few rounds of the chip's 512 workgroup slots, a partial last round of
     // 128-row tiles costs as much as a full one (a workgroup alone on a CU is not twice as fast), and half-size tiles halve that
-    // loss -- measured faster at every batch size from 625 to 5000 queries (lstm_tile = 2 forces 128 rows)
-    if (opt_lstm_tile() != 2) {
+    // loss -- measured faster at every batch size from 625 to 5000 queries (lstm_tile = 2 forces 128 rows).  Below ~700
+    // rows (a rank's share of the batch on 8 GPUs) the step is hardly more than one round and 32-row tiles at three
+    // workgroups per CU balance the CUs better still (tools/lstm_tile_sweep.py: -1 % at 625 rows, -11 % at 313; alone the
+    // encoder also gains 1-2 % at 1250 / 2500 rows, but beside the clip encoder on the other stream it does not; +5 % at 5000).
+    const int tile = opt_lstm_tile() ? opt_lstm_tile() : (g0.M <= 700 ? 3 : 1);
+    if (tile == 3) {                         // 32-row tiles, three workgroups per CU
+        dim3 grid((unsigned)cdiv(g0.M, 32), (unsigned)cdiv(g0.lstm_H, 32), 2);
+        hipLaunchKernelGGL(lstm_step_mfma_pair<0>, grid, dim3(256), 0, st, gp);
+    } else if (tile != 2) {
         dim3 grid((unsigned)cdiv(g0.M, 64), (unsigned)cdiv(g0.lstm_H, 32), 2);
         hipLaunchKernelGGL(lstm_step_mfma_pair<1>, grid, dim3(256), 0, st, gp);
     } else if (opt_gemm_pp()) {
