@@ -59,8 +59,8 @@ def site_work(site, cfg):
     B, C, Nv, H, E, F, hid, D, n, Nq = (cfg[k] for k in ("Bq", "C", "Nv", "H", "E", "F", "hid", "D", "n", "Nq"))
     M = n * (n + 1) // 2
     # threshold ladder of the top-k pass (score.hip: PRE_VIDEOS, PRE_LEVELS, pre_b_videos): stage A = the <=4-clip moments of
-    # 32 videos (its work is not counted: the sample is scored again in full by stage B), stage B = Nv/8 <= 1024 videos
-    nb = min(1024, Nv // 8) if Nv >= 256 else 0
+    # 32 videos (its work is not counted: the sample is scored again in full by stage B), stage B = Nv/16 <= 640 videos
+    nb = min(640, Nv // 16) if Nv >= 256 else 0
     table = {
         # fused step [x_t | h] x [Wih | Whh]^T; rows actually processed per launch, averaged over the T steps: the
         # forward direction steps every query (+1 all-pad row), the reverse direction only the queries that have
@@ -72,7 +72,7 @@ def site_work(site, cfg):
         "gemm_vis_out": 2.0 * C * D * hid,
         "gemm_lang_fc": 2.0 * B * D * 2 * H,
         # scoring launches (2nD contraction + n norms + 2M moment means per scoring).  With top-k the first
-        # Nv/8 (<= 1024) videos are stage B of the threshold ladder (site score_prepass, together with stage A's short-moment
+        # Nv/16 (<= 640) videos are stage B of the threshold ladder (site score_prepass, together with stage A's short-moment
         # pass over 32 of them); the main fused launch (top-k + rank keys, one distance pass) covers the rest.
         "score_fused": float(Nq) * max(Nv - nb, 0) * (2 * n * D + n + 2 * M),
         "score_rank": float(Nq) * Nv * (2 * n * D + n + 2 * M),          # k = 0 calls only

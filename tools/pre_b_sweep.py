@@ -6,7 +6,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import vfr_amd  # noqa
 from vfr_amd import _vfr
-nq, nv, n = 5000, 10000, 21
+import os
+nq, nv, n = 5000, int(os.environ.get("NV", 10000)), 21
 dev = "cuda:0"
 torch.manual_seed(0)
 V = torch.randn(nv * n, 100, device=dev) * 0.1

@@ -1048,14 +1048,14 @@ static int kpl_for(int k) { return k <= 128 ? 4 : 8; }
 // current threshold, so the threshold's quality decides how often its exact path runs:
 //   stage A  the short moments (<= PRE_LEVELS clips) of the first PRE_VIDEOS videos, one video per wave-task, threshold
 //            +inf -> merge -> their k-th key: a valid (any k keys bound the k-th best) and already tight bound, for 0.4 ms;
-//   stage B  the first pre_b_videos() videos (the sample included) under A's threshold -> merge: the k-th key of ~Nv/8
+//   stage B  the first pre_b_videos() videos (the sample included) under A's threshold -> merge: the k-th key of ~Nv/16 (<= 640; tools/pre_b_sweep.py: the optimum at 2500, 5000 and 10000 videos)
 //            videos, which admits only ~8k candidates per query in ...
 //   stage C  ... the rest of the corpus (the main launch); the final merge takes B's merged list as its `extra` input.
 // Every video's full moment set is scored exactly once (stage A's partial pass over 32 videos is the only repeated work).
 constexpr int PRE_VIDEOS = 32;
 constexpr int PRE_CHUNKS = 32;
 constexpr int PRE_LEVELS = 4;       // stage A keeps moments of at most this many clips
-static int pre_b_videos(int Nv) { if (opt_score_pre_b() > 0) return opt_score_pre_b() < Nv ? opt_score_pre_b() : Nv; const int b = Nv / 8; return b > 1024 ? 1024 : b; }
+static int pre_b_videos(int Nv) { if (opt_score_pre_b() > 0) return opt_score_pre_b() < Nv ? opt_score_pre_b() : Nv; const int b = Nv / 16; return b > 640 ? 640 : b; }
 
 struct TopkWs { unsigned long long *buf, *buf_pre, *pre_keys, *pre_keys2; int *cnt, *cnt_pre; unsigned long long *thr; size_t total; };
 static TopkWs carve_topk(void *base, int64_t Nq, int Nv, int k)
