@@ -141,8 +141,10 @@ def main():
     C_loc = int(off_all[hi] - off_all[lo])
 
     # ---- synthetic inputs, generated on the device (seeded), resident in HBM before timing ------------
-    gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
-    raw = torch.rand((C_loc, F), generator=gen, device=dev)
+    # every rank draws the SAME corpus (one seeded stream, 3.4 GB transient) and keeps its shard's rows, so the results --
+    # and the checksums in the JSON line -- are those of the single-GPU run whatever N is
+    gen = torch.Generator(device=dev); gen.manual_seed(1234)
+    raw = torch.rand((int(off_all[-1]), F), generator=gen, device=dev)[int(off_all[lo]):int(off_all[hi])].clone()
     seg = raw / (raw.norm(dim=1, keepdim=True) + 1e-5)
     clip_off = torch.from_numpy((off_all[lo:hi + 1] - off_all[lo]).astype(np.int32)).to(dev)
     nloc = (clip_off[1:] - clip_off[:-1]).long()

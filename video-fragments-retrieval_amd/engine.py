@@ -75,6 +75,23 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
+def _all_gather_rows(dist, out, mine):
+    """out[g] <- rank g's ``mine`` for a contiguous ``out [world, *mine.shape]``: ONE collective straight into the buffer
+    (``all_gather_into_tensor``; the list form makes the RCCL backend gather into a scratch tensor and copy the parts out).
+    Process groups without it (or stand-ins in tests) take the list form."""
+    fn = getattr(dist, "all_gather_into_tensor", None)
+    if fn is not None and not _all_gather_rows.list_only:
+        try:
+            fn(out, mine)
+            return
+        except (RuntimeError, NotImplementedError):
+            _all_gather_rows.list_only = True
+    dist.all_gather([out[g] for g in range(out.shape[0])], mine)
+
+
+_all_gather_rows.list_only = False
+
+
 @dataclass
 class CorpusShard:
     bank: object                 # ops.make_bank(...) result: clip embeddings + CSR offsets on the device
@@ -214,9 +231,9 @@ def encode_queries(model, tokens, device, ops=None, rank=0, world=1):
     if mine.shape[0] < per:                                   # pad so every rank gathers equal chunks
         mine = torch.cat([mine, tokens.new_zeros((per - mine.shape[0], tokens.shape[1]))])
     q = ops.encode_queries(model, mine.to(device))
-    parts = [torch.empty_like(q) for _ in range(world)]
-    dist.all_gather(parts, q)
-    return torch.cat(parts)[:Nq].contiguous()
+    parts = torch.empty((world,) + tuple(q.shape), dtype=q.dtype, device=q.device)
+    _all_gather_rows(dist, parts, q)
+    return parts.reshape(world * per, -1)[:Nq].contiguous()
 
 
 def gt_label_table(times, counts_own, thresholds, strict=True):
@@ -371,8 +388,7 @@ def sharded_search(shard: CorpusShard, Q, k, rank_dist, rank_idx, ops, world=1, 
     d_a, i_a, cnt = ops.score_topk(Q, bank_a, k, rank_dist, rank_idx, workspace=workspace)
     # exchange buffer: slot g < world = rank g's list, slot world = the global sample list (second exchange only)
     buf = torch.empty((world + 1,) + tuple(d_a.shape), dtype=torch.int64, device=d_a.device)
-    slots = [buf[g] for g in range(world)]
-    dist.all_gather(slots, ops.pack_keys(d_a, i_a))
+    _all_gather_rows(dist, buf[:world], ops.pack_keys(d_a, i_a))
     _, _, s_k = ops.merge_keys(buf[:world], want_lists=False, want_keys=True)   # global sample top-k, every rank
     buf[world].copy_(s_k)
     seed = s_k[:, k - 1].contiguous()                                           # its k-th key (KEY_INF if fewer than k)
@@ -384,7 +400,7 @@ def sharded_search(shard: CorpusShard, Q, k, rank_dist, rank_idx, ops, world=1, 
         mine = torch.full_like(s_k, KEY_INF)
     if cnt is not None:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    dist.all_gather(slots, mine)
+    _all_gather_rows(dist, buf[:world], mine)
     od, oi, _ = ops.merge_keys(buf)
     return od, oi, cnt
 
@@ -394,7 +410,7 @@ def gather_merge_topk(od, oi, ops, world, extra=None):
     then merge with the (distance, id) tie-break.  ``extra`` = an additional (dist, idx) list every rank holds."""
     dist = _dist()
     buf = torch.empty((world + (extra is not None),) + tuple(od.shape), dtype=torch.int64, device=od.device)
-    dist.all_gather([buf[g] for g in range(world)], ops.pack_keys(od, oi))
+    _all_gather_rows(dist, buf[:world], ops.pack_keys(od, oi))
     if extra is not None:
         ops.pack_keys(extra[0], extra[1], out=buf[world])
     d, i, _ = ops.merge_keys(buf)
