@@ -604,7 +604,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 }
 
 template <bool VEC, int MI = 2>
-__global__ __launch_bounds__(256, VFR_GEMM_NBUF == 1 ? 3 : 2) void gemm_nt_mfma(GemmArgs g) { gemm_nt_mfma_body<VEC, false, false, MI>(g); }
+__global__ __launch_bounds__(256, (VFR_GEMM_NBUF == 1 || MI == 0) ? 3 : 2) void gemm_nt_mfma(GemmArgs g) { gemm_nt_mfma_body<VEC, false, false, MI>(g); }
 
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp)
@@ -774,8 +774,18 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
         return VFR_OK;
     }
     const bool vec = gemm_vec_ok(g);
+    if (opt_gemm_small() != 64 && (int64_t)grid.x * grid.y < 384) {
+        // fewer 128-row workgroups than 1.5 per CU (context rows, output / query projections, VGG fc6-fc7): 32-row tiles at
+        // three workgroups per CU -- four times the workgroups, so the CUs are evenly loaded (tools/small_gemm.py: 10-40 %
+        // faster than 64-row tiles on every such GEMM of the pass; "gemm_small" 64 forces those)
+        dim3 grid32((unsigned)cdiv(g.M, 32), grid.y);
+        if (vec) hipLaunchKernelGGL((gemm_nt_mfma<true, 0>), grid32, dim3(256), 0, st, g);
+        else     hipLaunchKernelGGL((gemm_nt_mfma<false, 0>), grid32, dim3(256), 0, st, g);
+        VFR_CHECK_LAUNCH("gemm_nt_mfma<32>");
+        return VFR_OK;
+    }
     if ((int64_t)grid.x * grid.y < 384) {
-        // fewer workgroups than 1.5 per CU: the launch is one tile's latency, so halve the tile (64 rows)
+        // (cross-check build of the same class: 64-row tiles)
         dim3 grid64((unsigned)cdiv(g.M, 64), grid.y);
         if (vec) hipLaunchKernelGGL((gemm_nt_mfma<true, 1>), grid64, dim3(256), 0, st, g);
         else     hipLaunchKernelGGL((gemm_nt_mfma<false, 1>), grid64, dim3(256), 0, st, g);
