@@ -774,10 +774,12 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
         return VFR_OK;
     }
     const bool vec = gemm_vec_ok(g);
-    if (opt_gemm_small() != 64 && (int64_t)grid.x * grid.y < 384) {
+    if (opt_gemm_small() != 64 && (int64_t)grid.x * grid.y < (opt_gemm_small() > 64 ? opt_gemm_small() : 384)) {
         // fewer 128-row workgroups than 1.5 per CU (context rows, output / query projections, VGG fc6-fc7): 32-row tiles at
         // three workgroups per CU -- four times the workgroups, so the CUs are evenly loaded (tools/small_gemm.py: 10-40 %
-        // faster than 64-row tiles on every such GEMM of the pass; "gemm_small" 64 forces those)
+        // faster than 64-row tiles on every such GEMM of the pass; alone also 5 % at 824 tiles, a rank's clip encoder on 8 GPUs,
+        // but not beside the query encoder on the other stream; slower from ~1600 tiles on.  "gemm_small" 64 forces the 64-row
+        // tiles, a value above 64 moves the threshold)
         dim3 grid32((unsigned)cdiv(g.M, 32), grid.y);
         if (vec) hipLaunchKernelGGL((gemm_nt_mfma<true, 0>), grid32, dim3(256), 0, st, g);
         else     hipLaunchKernelGGL((gemm_nt_mfma<false, 0>), grid32, dim3(256), 0, st, g);
