@@ -12,7 +12,9 @@ from vfr_amd import _vfr
 
 dev = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and sys.argv[2].isdigit():
+    _vfr.set_option("gemm_small", int(sys.argv[2]))          # 1 = 64-row tiles for the large GEMMs (experiment)
+elif len(sys.argv) > 2:
     _vfr.LIB_PATH = Path(sys.argv[2]).resolve()
 torch.manual_seed(0)
 for name, M, K, N in (("lstm_rec  [5000x1000]x[4000x1000]^T", 5000, 1000, 4000), ("lstm step shape [5120x1152]x[4096x1152]^T", 5120, 1152, 4096),

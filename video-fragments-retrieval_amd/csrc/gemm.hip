@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
 #define VFR_GEMM_SETPRIO 0
 #endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int MBM = 128, MBN = 128, MBK = 32, MLD = 36;
+constexpr int MBM = 128, MBN = 128, MBK = 32, MLD_PAD = 36;
 
 template <bool VEC>
 __device__ __forceinline__ float4 load4_guard(const float *__restrict__ P, int64_t ld, int64_t row, int64_t nrows,
@@ -155,6 +155,12 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     constexpr int TBM = NARROW ? 128 * MI : (MI ? 64 * MI : 32);    // tile rows (MI = 0: the 32-row tile, one row tile per wave)
     constexpr int BN = NARROW ? 64 : MBN;               // tile columns
     constexpr int NA = TBM / 32, NW = BN / 32;          // float4 staging loads per thread of A / of W
+    // LDS row layout.  128-row tiles: 32 floats + 4 of padding (row stride 36: the 16 rows x 4 k's of a fragment read fall in
+    // 64 distinct banks).  Smaller tiles: NO padding, the eight 16-byte chunks of row r stored at chunk ^ ((r >> 1) & 7)
+    // instead -- equally conflict-free (bank = 32*(r&1) + 4*((k4 ^ (r>>1)) & 7) + q), and the 192-row double buffer is
+    // 48 KB instead of 54 KB, so THREE workgroups fit the CU's 160 KB where the padded layout stopped at two by 2 KB.
+    constexpr bool SWZ = MI <= 1 && !PP;
+    constexpr int MLD = SWZ ? 32 : MLD_PAD;
     // double-buffered tiles: [2][A TBMx36 | W 128x36] floats (73,728 B at MI = 2) -> two workgroups per CU
     constexpr int NBUF = PP ? 1 : (LSTM ? VFR_LSTM_NBUF : VFR_GEMM_NBUF);
     __shared__ __attribute__((aligned(16))) float lds_all[(PP ? 2 : 1) * NBUF * (TBM + BN) * MLD];
@@ -185,7 +191,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // accumulators: the wave's 16*TI x 64 outputs as TI x 4 tiles of v_mfma_f32_16x16x4_f32 (4 registers each); lane l holds
     // rows 4*(l>>4) + r (r = 0..3) and column l & 15 of a tile
     constexpr int TI = MI ? 2 * MI : 1;
-    const int l15 = lane & 15, lq = lane >> 4;
+    const int l15 = lane & 15, lq = lane >> 4, fsw = (l15 >> 1) & 7;
     f32x4 acc[TI][4];
     auto init_acc = [&]() {
         if (LSTM && g.lstm_tok) {
@@ -351,14 +357,14 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
             float4 v = ra[i];
             if (CONV || LSTM) { const bool z = za[i]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
-            *reinterpret_cast<float4 *>(&As[row * MLD + kk]) = v;
+            *reinterpret_cast<float4 *>(&As[row * MLD + (SWZ ? (((f & 7) ^ ((row >> 1) & 7)) << 2) : kk)]) = v;
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
             float4 v = rw[i];
             if (CONV || LSTM) { v.x = zw ? 0.f : v.x; v.y = zw ? 0.f : v.y; v.z = zw ? 0.f : v.z; v.w = zw ? 0.f : v.w; }
-            *reinterpret_cast<float4 *>(&Ws[row * MLD + kk]) = v;
+            *reinterpret_cast<float4 *>(&Ws[row * MLD + (SWZ ? (((f & 7) ^ ((row >> 1) & 7)) << 2) : kk)]) = v;
         }
     };
     auto compute = [&](int b) {
@@ -367,6 +373,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         // the 16x16x4 operand layout, read with ds_read_b32 (bank = 36*r + q mod 64: 64 distinct banks, conflict-free)
         const float *ap = &As[(wm * (16 * TI) + l15) * MLD + lq];
         const float *wp = &Ws[(wn * 64 + l15) * MLD + lq];
+        auto kcol = [&](int k4) { return SWZ ? ((k4 ^ fsw) << 2) : k4 * 4; };   // every fragment row has (row >> 1) & 7 == fsw
         // fragment ring: the reads of slice k4+DEPTH are issued (and pinned) BEFORE the MFMAs of slice k4, so their
         // latency hides under the matrix pipe.  DEPTH 2 matters when a workgroup is ALONE on its CU (partial last round, small
         // launches): with one slice of cover a lone wave's stream stalled on LDS latency and a half-filled round cost as much
@@ -376,18 +383,18 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
-            for (int ti = 0; ti < TI; ++ti) fa[d][ti] = ap[ti * 16 * MLD + d * 4];
+            for (int ti = 0; ti < TI; ++ti) fa[d][ti] = ap[ti * 16 * MLD + kcol(d)];
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj) fb[d][tj] = wp[tj * 16 * MLD + d * 4];
+            for (int tj = 0; tj < 4; ++tj) fb[d][tj] = wp[tj * 16 * MLD + kcol(d)];
         }
 #pragma unroll
         for (int k4 = 0; k4 < MBK / 4; ++k4) {
             const int cur = k4 % RING, nxt = (k4 + DEPTH) % RING;
             if (k4 + DEPTH < MBK / 4) {
 #pragma unroll
-                for (int ti = 0; ti < TI; ++ti) fa[nxt][ti] = ap[ti * 16 * MLD + (k4 + DEPTH) * 4];
+                for (int ti = 0; ti < TI; ++ti) fa[nxt][ti] = ap[ti * 16 * MLD + kcol(k4 + DEPTH)];
 #pragma unroll
-                for (int tj = 0; tj < 4; ++tj) fb[nxt][tj] = wp[tj * 16 * MLD + (k4 + DEPTH) * 4];
+                for (int tj = 0; tj < 4; ++tj) fb[nxt][tj] = wp[tj * 16 * MLD + kcol(k4 + DEPTH)];
             }
             __builtin_amdgcn_sched_barrier(0);
             // one MFMA = k, k+1, k+2, k+3 in order on top of the accumulator: the oracle's chain
@@ -435,8 +442,9 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         float fa[RING][TI], fb[RING][4];
         auto frag_read = [&](int buf, int slice, int slot) {
             const float *As = lds + buf * (TBM + BN) * MLD, *Ws = As + TBM * MLD;
-            const float *ap = &As[(wm * (16 * TI) + l15) * MLD + lq + slice * 4];
-            const float *wp = &Ws[(wn * 64 + l15) * MLD + lq + slice * 4];
+            const int kc = SWZ ? ((slice ^ fsw) << 2) : slice * 4;
+            const float *ap = &As[(wm * (16 * TI) + l15) * MLD + lq + kc];
+            const float *wp = &Ws[(wn * 64 + l15) * MLD + lq + kc];
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti) fa[slot][ti] = ap[ti * 16 * MLD];
 #pragma unroll
@@ -604,7 +612,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 }
 
 template <bool VEC, int MI = 2>
-__global__ __launch_bounds__(256, (VFR_GEMM_NBUF == 1 || MI == 0) ? 3 : 2) void gemm_nt_mfma(GemmArgs g) { gemm_nt_mfma_body<VEC, false, false, MI>(g); }
+__global__ __launch_bounds__(256, (VFR_GEMM_NBUF == 1 || MI <= 1) ? 3 : 2) void gemm_nt_mfma(GemmArgs g) { gemm_nt_mfma_body<VEC, false, false, MI>(g); }
 
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp)
@@ -614,10 +622,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp)
 }
 
 template <int MI = 2, bool NARROW = false>
-__global__ __launch_bounds__(256, 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true, false, MI, false, NARROW>(g); }
+__global__ __launch_bounds__(256, MI <= 1 ? 3 : 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true, false, MI, false, NARROW>(g); }
 
 template <int MI>
-__global__ __launch_bounds__(256, MI ? VFR_LSTM_WAVES : 3) void lstm_step_mfma_pair(GemmPair gp)
+__global__ __launch_bounds__(256, MI <= 1 ? 3 : VFR_LSTM_WAVES) void lstm_step_mfma_pair(GemmPair gp)
 {
     const GemmArgs g = gp.p[blockIdx.z];      // private copy, see gemm_nt_mfma_pair
     gemm_nt_mfma_body<true, false, true, MI>(g);
@@ -795,6 +803,17 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
         return VFR_OK;
     }
     const bool pp = opt_gemm_pp() && (g.K % MBK) == 0 && g.K >= 2 * MBK;
+    if (opt_gemm_small() == 1) {             // experiment: 64-row tiles (three workgroups per CU) for the large GEMMs too
+        const unsigned gx64 = (unsigned)cdiv(g.M, 64);
+        GemmArgs gx = g;
+        const bool xcd = grid.y > 1 && grid.y <= 16 && gx64 >= 64;
+        gx.xcd_cols = xcd ? (int)grid.y : 0;
+        dim3 gr = xcd ? dim3((unsigned)(cdiv(gx64, 8) * 8 * grid.y)) : dim3(gx64, grid.y);
+        if (vec) hipLaunchKernelGGL((gemm_nt_mfma<true, 1>), gr, dim3(256), 0, st, gx);
+        else     hipLaunchKernelGGL((gemm_nt_mfma<false, 1>), gr, dim3(256), 0, st, gx);
+        VFR_CHECK_LAUNCH("gemm_nt_mfma<64>(large)");
+        return VFR_OK;
+    }
     if (grid.y > 1 && grid.y <= 16 && grid.x >= 64) {
         // tall GEMM with a few column tiles (the clip encoder's seg x W1: 1641 x 4): XCD-aware tile order, see xcd_cols
         GemmArgs gx = g;
