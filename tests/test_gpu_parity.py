@@ -456,13 +456,15 @@ def test_bilstm_tile_shapes_agree(vfr, oracle):
     assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])
     want = oracle.bilstm_final(tokens[:64], sd["word_embedding.weight"], lstm_of(sd), sd["lang_fc.weight"], sd["lang_fc.bias"])
     assert same(outs[2][:64], want)
-    # the first step skips its recurrent segment (h_0 = 0 -> every term is fma(0, w, acc) == acc): same bits as running it
-    try:
-        vfr.set_option("lstm_skip0", 0)
-        full = vfr.bilstm_final(*args)
-    finally:
-        vfr.set_option("lstm_skip0", 1)
-    assert torch.equal(full.view(torch.int32), outs[1].view(torch.int32))
+    # the first step skips its recurrent segment (h_0 = 0 -> every term is fma(0, w, acc) == acc): same bits as running it;
+    # the XCD-aware workgroup order is a permutation of the same tiles
+    for opt in ("lstm_skip0", "lstm_xcd"):
+        try:
+            vfr.set_option(opt, 0)
+            other = vfr.bilstm_final(*args)
+        finally:
+            vfr.set_option(opt, 1)
+        assert torch.equal(other.view(torch.int32), outs[1].view(torch.int32)), opt
 
 
 @pytest.mark.gpu

@@ -170,7 +170,18 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     const int wm = NARROW ? wave : wave >> 1, wn = NARROW ? 0 : wave & 1;
     int64_t m0 = (int64_t)(PP ? blockIdx.x * 2 + grp : blockIdx.x) * TBM;
     int n0 = blockIdx.y * BN;
+    int by = blockIdx.y;                                 // column tile (LSTM step: 4 gates x 32 units)
     bool active = true;                                  // PP: a group without a tile still takes part in the barriers
+    if (LSTM && g.xcd_cols > 0) {
+        // XCD-aware order of the fused step (1-D grid per direction; workgroup L runs on XCD L % 8): each XCD owns xcd_cols
+        // adjacent column tiles -- its 2 MB slice of W_hh stays in its 4 MB L2 for the whole launch -- and walks the row
+        // tiles with the column tile fastest, so the xcd_cols workgroups that share an h row tile run together.  In launch
+        // order every XCD touched all 16 MB of W_hh: 1.3 GB of L2 misses per launch for 72 MB of operands.
+        const unsigned L = blockIdx.x, j = L >> 3, cpx = (unsigned)g.xcd_cols;
+        by = (int)((L & 7u) * cpx + j % cpx);
+        m0 = (int64_t)(j / cpx) * TBM;
+        if (by * 32 >= g.lstm_H) return;                 // grid padded to 8 * xcd_cols column tiles
+    }
     if (!LSTM && g.xcd_cols > 0) {
         const unsigned L = blockIdx.x, per = 8u * (unsigned)g.xcd_cols, within = L % per;
         const int64_t rt = (int64_t)(L / per) * 8 + (within & 7u);
@@ -205,7 +216,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                     const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq + r;
                     prow[ti][r] = (int64_t)g.lstm_tok[row < Mrows ? row : Mrows - 1];
                 }
-            const float *pcol = g.Cin + (int64_t)blockIdx.y * MBN + wn * 64 + l15;
+            const float *pcol = g.Cin + (int64_t)by * MBN + wn * 64 + l15;
     #pragma unroll
             for (int ti = 0; ti < TI; ++ti)
     #pragma unroll
@@ -243,7 +254,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         int64_t nw = (int64_t)n0 + row < g.N ? (int64_t)n0 + row : g.N - 1;
         if (LSTM) {   // tile column c = (wn, tj, l15): gate = tj = (c >> 4) & 3, unit = 32*blockIdx.y + 16*wn + (c & 15)
             const int gate = (row >> 4) & 3;
-            int unit = blockIdx.y * 32 + (row >> 6) * 16 + (row & 15);
+            int unit = by * 32 + (row >> 6) * 16 + (row & 15);
             unit = unit < g.lstm_H ? unit : g.lstm_H - 1;
             nw = (int64_t)gate * g.lstm_H + unit;
             wrow2[i] = g.W2 + nw * g.ldw2 + kk;
@@ -523,7 +534,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     if (LSTM) {
         // tile columns are (gate, unit): a lane holds i, f, g, o of unit 32*blockIdx.y + 16*wn + (lane & 15) in its four column
         // tiles, for 4*TI rows -- every cell is finished by ONE lane, no exchange
-        const int H = g.lstm_H, unit = blockIdx.y * 32 + wn * 16 + l15;
+        const int H = g.lstm_H, unit = by * 32 + wn * 16 + l15;
         const bool valid = unit < H;
         const int uc = valid ? unit : H - 1;
         const float bi = g.bias[uc] + g.bias2[uc], bf = g.bias[H + uc] + g.bias2[H + uc];
@@ -705,18 +716,22 @@ int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
     // workgroups per CU balance the CUs better still (tools/lstm_tile_sweep.py: -1 % at 625 rows, -11 % at 313; alone the
     // encoder also gains 1-2 % at 1250 / 2500 rows, but beside the clip encoder on the other stream it does not; +5 % at 5000).
     const int tile = opt_lstm_tile() ? opt_lstm_tile() : (g0.M <= 700 ? 3 : 1);
+    const int ncol = (int)cdiv(g0.lstm_H, 32), cpx = (int)cdiv(ncol, 8);
+    const bool xcd = opt_lstm_xcd() && !(tile == 2 && opt_gemm_pp());
+    if (xcd) gp.p[0].xcd_cols = gp.p[1].xcd_cols = cpx;
+    auto grid_for = [&](int rows) {
+        const unsigned rt = (unsigned)cdiv(g0.M, rows);
+        return xcd ? dim3(rt * (unsigned)cpx * 8u, 1, 2) : dim3(rt, (unsigned)ncol, 2);
+    };
     if (tile == 3) {                         // 32-row tiles, three workgroups per CU
-        dim3 grid((unsigned)cdiv(g0.M, 32), (unsigned)cdiv(g0.lstm_H, 32), 2);
-        hipLaunchKernelGGL(lstm_step_mfma_pair<0>, grid, dim3(256), 0, st, gp);
+        hipLaunchKernelGGL(lstm_step_mfma_pair<0>, grid_for(32), dim3(256), 0, st, gp);
     } else if (tile != 2) {
-        dim3 grid((unsigned)cdiv(g0.M, 64), (unsigned)cdiv(g0.lstm_H, 32), 2);
-        hipLaunchKernelGGL(lstm_step_mfma_pair<1>, grid, dim3(256), 0, st, gp);
+        hipLaunchKernelGGL(lstm_step_mfma_pair<1>, grid_for(64), dim3(256), 0, st, gp);
     } else if (opt_gemm_pp()) {
         dim3 grid((unsigned)cdiv(cdiv(g0.M, MBM), 2), (unsigned)cdiv(g0.lstm_H, 32), 2);
         hipLaunchKernelGGL(lstm_step_mfma_pair_pp, grid, dim3(512), 0, st, gp);
     } else {
-        dim3 grid((unsigned)cdiv(g0.M, MBM), (unsigned)cdiv(g0.lstm_H, 32), 2);
-        hipLaunchKernelGGL(lstm_step_mfma_pair<2>, grid, dim3(256), 0, st, gp);
+        hipLaunchKernelGGL(lstm_step_mfma_pair<2>, grid_for(MBM), dim3(256), 0, st, gp);
     }
     VFR_CHECK_LAUNCH("lstm_step_mfma_pair");
 #ifdef VFR_GEMM_STAMPS

@@ -14,6 +14,7 @@ static int g_opt_profile = 0;
 static int g_opt_score_fast = 1;
 static int g_opt_score_split = 0;
 static int g_opt_gemm_small = 0;       // small dense GEMMs: 0 = 32-row tiles, 64 = 64-row tiles (cross-check)
+static int g_opt_lstm_xcd = 1;         // 1: XCD-aware workgroup order of the fused LSTM step; 0: launch order (cross-check)
 static int g_opt_lstm_skip0 = 1;       // 1: the first LSTM step skips its recurrent segment (h_0 = 0); 0: runs it (cross-check)
 static int g_opt_score_tasks = 0;      // > 0: wave-tasks the scorer's plan aims for (experiment; 0 = automatic)
 static int g_opt_score_pre_b = 0;      // > 0: videos in ladder stage B (experiment; 0 = Nv/8 capped at 1024)
@@ -66,6 +67,7 @@ int opt_score_split() { return g_opt_score_split; }
 int opt_score_pre_b() { return g_opt_score_pre_b; }
 int opt_score_tasks() { return g_opt_score_tasks; }
 int opt_lstm_skip0() { return g_opt_lstm_skip0; }
+int opt_lstm_xcd() { return g_opt_lstm_xcd; }
 int opt_gemm_small() { return g_opt_gemm_small; }
 int opt_lstm_tile() { return g_opt_lstm_tile; }
 int opt_gemm_pp() { return g_opt_gemm_pp; }
@@ -103,6 +105,7 @@ int vfr_set_option(const char *name, int value)
     if (name && !strcmp(name, "score_pre_b")) { vfr::g_opt_score_pre_b = value; return VFR_OK; }
     if (name && !strcmp(name, "score_tasks")) { vfr::g_opt_score_tasks = value; return VFR_OK; }
     if (name && !strcmp(name, "lstm_skip0")) { vfr::g_opt_lstm_skip0 = value; return VFR_OK; }
+    if (name && !strcmp(name, "lstm_xcd")) { vfr::g_opt_lstm_xcd = value; return VFR_OK; }
     if (name && !strcmp(name, "gemm_small")) { vfr::g_opt_gemm_small = value; return VFR_OK; }
     if (name && !strcmp(name, "lstm_tile")) { vfr::g_opt_lstm_tile = value; return VFR_OK; }
     if (name && !strcmp(name, "gemm_pp")) { vfr::g_opt_gemm_pp = value; return VFR_OK; }
@@ -117,6 +120,7 @@ int vfr_get_option(const char *name)
     if (name && !strcmp(name, "score_pre_b")) return vfr::g_opt_score_pre_b;
     if (name && !strcmp(name, "score_tasks")) return vfr::g_opt_score_tasks;
     if (name && !strcmp(name, "lstm_skip0")) return vfr::g_opt_lstm_skip0;
+    if (name && !strcmp(name, "lstm_xcd")) return vfr::g_opt_lstm_xcd;
     if (name && !strcmp(name, "gemm_small")) return vfr::g_opt_gemm_small;
     if (name && !strcmp(name, "lstm_tile")) return vfr::g_opt_lstm_tile;
     if (name && !strcmp(name, "gemm_pp")) return vfr::g_opt_gemm_pp;

@@ -22,6 +22,7 @@ int opt_score_split();
 int opt_score_pre_b();
 int opt_score_tasks();
 int opt_lstm_skip0();
+int opt_lstm_xcd();
 int opt_gemm_small();
 int opt_lstm_tile();
 int opt_gemm_pp();
