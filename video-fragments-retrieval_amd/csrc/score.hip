@@ -1286,6 +1286,7 @@ static int launch_merge_parts(const float *pd, const int64_t *pi, bool packed, i
 {
     dim3 grid((unsigned)vfr::cdiv(Nq, 4)), block(256);
     const int kpl = vfr::kpl_for(k);
+    vfr::ProfScope prof(vfr::SITE_EXCHANGE, vfr::as_stream(stream));
 #define VFR_MERGE(KPL, PACKED) hipLaunchKernelGGL((vfr::topk_merge_parts_kernel<KPL, PACKED>), grid, block, 0, \
                                                   vfr::as_stream(stream), pd, pi, G, Nq, k, od, oi, okeys)
     if (packed) { if (kpl == 4) VFR_MERGE(4, true); else VFR_MERGE(8, true); }
@@ -1310,6 +1311,7 @@ int vfr_topk_pack_keys(const float *dist, const int64_t *idx, int64_t n, int64_t
 {
     VFR_REQUIRE(n >= 0 && (n == 0 || (dist && idx && keys)), VFR_EINVAL, "vfr_topk_pack_keys: bad argument");
     if (n == 0) return VFR_OK;
+    vfr::ProfScope prof(vfr::SITE_EXCHANGE, vfr::as_stream(stream));
     hipLaunchKernelGGL(vfr::topk_pack_keys_kernel, dim3((unsigned)vfr::cdiv(n, 256)), dim3(256), 0,
                        vfr::as_stream(stream), dist, idx, n, keys);
     VFR_CHECK_LAUNCH("topk_pack_keys_kernel");
@@ -1335,6 +1337,7 @@ int vfr_gt_best_keys_f32(const float *own_scores, int64_t n_sel, int M, int scor
                 "vfr_gt_best_keys_f32: bad argument");
     VFR_REQUIRE(n_sel == 0 || (own_scores && labels && id_base && sel), VFR_EINVAL, "vfr_gt_best_keys_f32: null input");
     if (Nq == 0) return VFR_OK;
+    vfr::ProfScope prof(vfr::SITE_EXCHANGE, vfr::as_stream(stream));
     hipLaunchKernelGGL(vfr::gt_fill_keys_kernel, dim3((unsigned)vfr::cdiv((int64_t)R * Nq, 256)), dim3(256), 0,
                        vfr::as_stream(stream), (int64_t)R * Nq, keys);
     VFR_CHECK_LAUNCH("gt_fill_keys_kernel");

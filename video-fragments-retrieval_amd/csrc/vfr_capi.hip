@@ -134,7 +134,7 @@ const char *vfr_profile_site_name(int site)
     static const char *names[vfr::SITE_COUNT] = {
         "none", "gemm_vis_seg", "gemm_vis_ctx", "vis_hidden", "gemm_vis_out", "embed", "gemm_lstm_in", "gemm_lstm_rec",
         "lstm_pointwise", "gemm_lang_fc", "score_fused", "topk_merge", "score_dense", "score_own", "pool", "linear",
-        "conv3x3", "pool2d", "normalize", "score_rank", "score_prepass", "repack"};
+        "conv3x3", "pool2d", "normalize", "score_rank", "score_prepass", "repack", "exchange"};
     return site >= 0 && site < vfr::SITE_COUNT ? names[site] : "?";
 }
 
