@@ -58,8 +58,8 @@ def site_work(site, cfg):
     """Algorithmic FLOP per launch of an instrumented site (SURVEY.md 8d figures), and which roof bounds it."""
     B, C, Nv, H, E, F, hid, D, n, Nq = (cfg[k] for k in ("Bq", "C", "Nv", "H", "E", "F", "hid", "D", "n", "Nq"))
     M = n * (n + 1) // 2
-    # threshold ladder of the top-k pass (score.hip: PRE_VIDEOS, PRE_LEVELS, pre_b_videos): stage A = the <=4-clip moments of
-    # 32 videos (its work is not counted: the sample is scored again in full by stage B), stage B = Nv/16 <= 640 videos
+    # threshold ladder of the top-k pass (score.hip: PRE_VIDEOS, PRE_LEVELS, pre_b_videos): stage A = the 1- and 2-clip moments of
+    # 64 videos (its work is not counted: the sample is scored again in full by stage B), stage B = Nv/16 <= 640 videos
     nb = min(640, Nv // 16) if Nv >= 256 else 0
     table = {
         # fused step [x_t | h] x [Wih | Whh]^T; rows actually processed per launch, averaged over the T steps: the

@@ -15,7 +15,7 @@ from pathlib import Path
 import torch
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libvfr.so"
+LIB_PATH = Path(os.environ["VFR_LIB"]).resolve() if os.environ.get("VFR_LIB") else _PKG / "lib" / "libvfr.so"   # VFR_LIB: A/B another build
 _lib = None
 
 _vp, _i32, _i64, _f32, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t

@@ -1051,10 +1051,10 @@ static int kpl_for(int k) { return k <= 128 ? 4 : 8; }
 //   stage B  the first pre_b_videos() videos (the sample included) under A's threshold -> merge: the k-th key of ~Nv/16 (<= 640; tools/pre_b_sweep.py: the optimum at 2500, 5000 and 10000 videos)
 //            videos, which admits only ~8k candidates per query in ...
 //   stage C  ... the rest of the corpus (the main launch); the final merge takes B's merged list as its `extra` input.
-// Every video's full moment set is scored exactly once (stage A's partial pass over 32 videos is the only repeated work).
-constexpr int PRE_VIDEOS = 32;
-constexpr int PRE_CHUNKS = 32;
-constexpr int PRE_LEVELS = 4;       // stage A keeps moments of at most this many clips
+// Every video's full moment set is scored exactly once (stage A's partial pass over 64 videos is the only repeated work).
+constexpr int PRE_VIDEOS = 64;
+constexpr int PRE_CHUNKS = 64;
+constexpr int PRE_LEVELS = 2;       // stage A keeps moments of at most this many clips
 static int pre_b_videos(int Nv) { if (opt_score_pre_b() > 0) return opt_score_pre_b() < Nv ? opt_score_pre_b() : Nv; const int b = Nv / 16; return b > 640 ? 640 : b; }
 
 struct TopkWs { unsigned long long *buf, *buf_pre, *pre_keys, *pre_keys2; int *cnt, *cnt_pre; unsigned long long *thr; size_t total; };
@@ -1228,10 +1228,10 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
             if (e != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: threshold initialisation failed");
         }
         // threshold ladder (see PRE_VIDEOS).  Stage A needs no seed and runs for every bank size (a 32-video sample shard is
-        // just a stage A); a caller-provided seed (the multi-GPU sample) replaces it.  Stage B only pays off on a long rest.
+        // just a stage A plus its main pass); a caller-provided seed (the multi-GPU sample) replaces it.  Stage B only pays off on a long rest.
         const bool fast = k > 0 && vfr::fast_applicable(a);
         const int na = (fast && !thr_seed) ? (Nv < vfr::PRE_VIDEOS ? Nv : vfr::PRE_VIDEOS) : 0;
-        // (after stage A's 32 videos an eighth of any corpus >= 256 tightens a lot; after a seed -- normally the k-th key of
+        // (after stage A's 64 videos a sixteenth of any corpus >= 256 tightens a lot; after a seed -- normally the k-th key of
         // a 256-video global sample -- only a stage B of >= 512 videos can tighten further)
         const int nb = (fast && Nv >= (thr_seed ? 4096 : 256)) ? vfr::pre_b_videos(Nv) : 0;
         if (k > 0 && !fast && !thr_seed && Nv <= 512) {
