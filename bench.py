@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--feat-dim", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="vfr_set_option passthrough for parameter sweeps (results must not change: compare the checksums)")
     ap.add_argument("--host-feed", action="store_true",
                     help="also time the pass with the pooled features in pinned HOST memory (PCIe-inclusive; extra field, never `value`)")
     ap.add_argument("--cpu-sample", default="1024x4000", help="queries x videos for the CPU baseline sample")
@@ -116,6 +118,9 @@ def main():
     import vfr_amd  # noqa: F401
     from vfr_amd import _vfr, engine, models, synth
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU substitute)"
+    for item in args.opt:
+        name, value = item.split("=")
+        _vfr.set_option(name, int(value))
     # rehearsal switches (not used by the driver): VFR_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and
     # VFR_BENCH_BACKEND=gloo swaps RCCL for gloo, so the multi-rank code path can be exercised on a one-GPU box
     if os.environ.get("VFR_BENCH_SAME_DEVICE"):
