@@ -12,8 +12,9 @@ from vfr_amd import _vfr
 
 dev = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-if len(sys.argv) > 2 and sys.argv[2].isdigit():
-    _vfr.set_option("gemm_small", int(sys.argv[2]))          # 1 = 64-row tiles for the large GEMMs (experiment)
+MODE = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else None   # gemm_small: 1 = 64-row tiles for the large GEMMs (experiment); also
+if MODE is not None:                                                                 # checks the bits against the default path
+    pass
 elif len(sys.argv) > 2:
     _vfr.LIB_PATH = Path(sys.argv[2]).resolve()
 torch.manual_seed(0)
@@ -22,10 +23,14 @@ for name, M, K, N in (("lstm_rec  [5000x1000]x[4000x1000]^T", 5000, 1000, 4000),
                       ("square 4096^3", 4096, 4096, 4096)):
     A = torch.randn(M, K, device=dev)
     W = torch.randn(N, K, device=dev)
-    _vfr.linear(A, W); torch.cuda.synchronize()
+    ref = _vfr.linear(A, W)
+    if MODE is not None:
+        _vfr.set_option("gemm_small", MODE)
+    same = torch.equal(_vfr.linear(A, W), ref); torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(reps):
         _vfr.linear(A, W)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t) / reps * 1e3
-    print(f"{name:40s} {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:7.1f} TFLOP/s", flush=True)
+    _vfr.set_option("gemm_small", 0)
+    print(f"{name:40s} {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:7.1f} TFLOP/s" + (f"   same bits as default: {same}" if MODE is not None else ""), flush=True)
