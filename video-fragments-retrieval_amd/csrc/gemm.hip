@@ -91,6 +91,9 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
 #ifndef VFR_LSTM_NBUF
 #define VFR_LSTM_NBUF 2      // the fused LSTM step's own choice (experiment switch)
 #endif
+#ifndef VFR_GLOAD_SLICE
+#define VFR_GLOAD_SLICE 3      /* k-slice of a K-tile after which the global loads of K-tile kt+2 are issued (1, 2: within run-to-run noise) */
+#endif
 #ifndef VFR_GEMM_PIPE
 #define VFR_GEMM_PIPE 1      // 1: K-tile loop software-pipelined across the tile boundary (see the main loop); 0: the plain loop
 #endif
@@ -490,7 +493,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                         acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k4 % RING][ti], fb[k4 % RING][tj], acc[ti][tj], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (k4 == 1) swrite(nb);
-                if (k4 == 3) { const int t2 = kt + 2 < nk ? kt + 2 : nk - 1; gload_main(t2 * MBK); }
+                if (k4 == VFR_GLOAD_SLICE) { const int t2 = kt + 2 < nk ? kt + 2 : nk - 1; gload_main(t2 * MBK); }
             }
         }
         if (!CONV && !LSTM && (g.K % MBK)) {   // partial last tile: guarded loads, zero padded (fma(0,0,acc) == acc)
