@@ -215,3 +215,35 @@ def test_feature_store_rejects_damaged_files():
             FeatureStore.write(p, ["a", "b"], [0, 2, 4], rs.rand(2, 8), rs.rand(5, 8))
         FeatureStore.write(p, [], [0], np.zeros((0, 8)), np.zeros((0, 8)))                       # empty corpus
         assert FeatureStore.open(p).feature_bank().seg.shape[0] == 0
+
+
+def test_engine_exchange_helpers_on_cpu():
+    """engine.overlapped degrades to two plain calls off the GPU; _all_gather_rows falls back to the list form when the
+    process group has no all_gather_into_tensor (or refuses it) and remembers that."""
+    from vfr_amd import engine
+    assert engine.overlapped("cpu", lambda: 1, lambda: 2) == (1, 2)
+    assert engine.overlapped("cuda:0", lambda: "a", lambda: "b", enable=False) == ("a", "b")
+
+    class ListOnly:
+        calls = 0
+
+        def all_gather(self, parts, t):
+            ListOnly.calls += 1
+            for g, p in enumerate(parts):
+                p.copy_(t + g)
+
+    class Refuses(ListOnly):
+        def all_gather_into_tensor(self, out, t):
+            raise RuntimeError("not supported by this backend")
+
+    mine = torch.arange(6, dtype=torch.int64).reshape(2, 3)
+    old = engine._all_gather_rows.list_only
+    try:
+        for group in (ListOnly(), Refuses()):
+            engine._all_gather_rows.list_only = False
+            out = torch.empty((3, 2, 3), dtype=torch.int64)
+            engine._all_gather_rows(group, out, mine)
+            assert all(torch.equal(out[g], mine + g) for g in range(3))
+        assert engine._all_gather_rows.list_only is True and ListOnly.calls == 2
+    finally:
+        engine._all_gather_rows.list_only = old
