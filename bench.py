@@ -177,10 +177,10 @@ def main():
 
     def step():
         with torch.no_grad():
-            # a rank's two encoders are small enough at N > 1 to leave CUs idle in their partial tile rounds: run them side
-            # by side there; at N = 1 they stay back to back (the per-kernel durations quoted in `roofline` are then undisturbed)
+            # a rank's two encoders are small enough from N = 4 on to leave CUs idle in their partial tile rounds: run them side
+            # by side there (tools/rank_sim.py: -0.16 ms at 8, -0.09 at 4, +0.08 at 2); below they stay back to back (the per-kernel durations quoted in `roofline` are then undisturbed)
             emb, Q = engine.overlapped(dev, lambda: model.encode_clips(seg, ctx, clip_off),
-                                       lambda: engine.encode_queries(model, tokens, dev, ops, rank, world), enable=world > 1)
+                                       lambda: engine.encode_queries(model, tokens, dev, ops, rank, world), enable=world >= 4)
             return engine.corpus_ranks(make_shard(emb), Q, own, labels, ops, k=args.k, world=world, workspace=ws, gt=gt)
 
     def barrier():

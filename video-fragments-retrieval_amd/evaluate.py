@@ -60,12 +60,12 @@ def embed_corpus(model, video_iterator, device, ops, rank=0, world=1, drained=No
 
 
 def _encode_both(model, video_iterator, drained, tokens, device, ops, rank, world, query_fn=None):
-    """Clip shard and query batch; on a sharded run the two independent encoders run side by side (engine.overlapped)."""
+    """Clip shard and query batch; from 4 shards on the two independent encoders run side by side (engine.overlapped)."""
     def queries():
         with torch.no_grad():
             return query_fn() if query_fn else engine.encode_queries(model, torch.cat(tokens), device, ops, rank, world)
     (shard, names), Q = engine.overlapped(device, lambda: embed_corpus(model, video_iterator, device, ops, rank, world, drained),
-                                          queries, enable=world > 1 and len(tokens) > 0)
+                                          queries, enable=world >= 4 and len(tokens) > 0)
     return shard, names, Q
 
 
