@@ -164,7 +164,13 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.to(dev).eval()
     ops = engine.HipOps()
-    labels = engine.gt_label_table(times, counts_all[own], [0.5, 0.7])
+    # a11 inputs resident on the device: the annotators' spans of every query, the clip count of its own video
+    t_h, na_h = engine.pack_times(times)
+    times_dev = (torch.from_numpy(t_h).to(dev), torch.from_numpy(na_h).to(dev))
+    n_own_dev = torch.from_numpy(counts_all[own].astype(np.int32)).to(dev)
+    nmax_own = int(counts_all[own].max())
+    Mmax_own = nmax_own * (nmax_own + 1) // 2
+    IOU = [0.5, 0.7]
 
     def make_shard(emb):
         bank = _vfr.VideoBank(emb, clip_off, int(mom_all[lo]), max_clips=int(counts_all[lo:hi].max()),
@@ -172,8 +178,14 @@ def main():
         return engine.CorpusShard(bank, lo, hi, counts_all, mom_all, dev)
 
     with torch.no_grad():
-        gt = engine.prepare_gt(make_shard(model.encode_clips(seg, ctx, clip_off)), own, labels)
+        gt_idx = engine.gt_index(make_shard(model.encode_clips(seg, ctx, clip_off)), own)    # which queries this shard owns
     ws = _vfr.topk_workspace(Nq, hi - lo, args.k, dev)
+
+    def ranks_of(shard, Q):
+        # a11 inside the step: the label table of the batch (model/evaluate.py:59-65) is rebuilt from the spans every pass
+        labels = ops.gt_labels(times_dev, n_own_dev, IOU, True, dev, Mmax=Mmax_own)
+        gt = engine.prepare_gt(shard, own, labels, index=gt_idx)
+        return engine.corpus_ranks(shard, Q, own, labels, ops, k=args.k, world=world, workspace=ws, gt=gt)
 
     def step():
         with torch.no_grad():
@@ -181,7 +193,7 @@ def main():
             # by side there (tools/rank_sim.py: -0.16 ms at 8, -0.09 at 4, +0.08 at 2); below they stay back to back (the per-kernel durations quoted in `roofline` are then undisturbed)
             emb, Q = engine.overlapped(dev, lambda: model.encode_clips(seg, ctx, clip_off),
                                        lambda: engine.encode_queries(model, tokens, dev, ops, rank, world), enable=world >= 4)
-            return engine.corpus_ranks(make_shard(emb), Q, own, labels, ops, k=args.k, world=world, workspace=ws, gt=gt)
+            return ranks_of(make_shard(emb), Q)
 
     def barrier():
         if dist is not None:
@@ -222,7 +234,7 @@ def main():
                     Q = engine.encode_queries(model, tokens, dev, ops, rank, world)
                 shard = make_shard(engine.encode_clips_streamed(ops, model, seg_h, ctx_h, off_h, dev))
                 torch.cuda.current_stream(dev).wait_stream(qs)
-                return engine.corpus_ranks(shard, Q, own, labels, ops, k=args.k, world=world, workspace=ws, gt=gt)
+                return ranks_of(shard, Q)
         out_h = step_host()
         torch.cuda.synchronize()
         th = time.perf_counter()

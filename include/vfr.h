@@ -15,8 +15,12 @@
  *     no entry point synchronises with the host
  *   - return 0 on success, a negative VFR_E* code otherwise; vfr_last_error() gives the message
  *     (thread-local).  No exception, exit or abort crosses the boundary.
- *   - stateless and re-entrant; weights are passed per call (no hidden model handle), so
- *     load_state_dict()/.to() on the Python side keep working
+ *   - no model state: weights are passed per call (no hidden model handle), so load_state_dict()/.to()
+ *     on the Python side keep working.  Compute entry points are re-entrant: any number of host threads
+ *     may call them concurrently (each on its own stream or sharing one).  The only process-wide state
+ *     is the tuning options (vfr_set_option: atomic ints read once per call -- a knob for tests and
+ *     sweeps, every setting gives the same bits) and the launch-site profiler (off by default; event
+ *     pairs are owned by the calling scope, the totals are folded under a mutex)
  *   - numerics: every contraction is one k-ascending fp32 fma chain (what the fp32 MFMAs
  *     compute), so results are bit-identical to oracle/vfr_oracle.c on any input
  */
@@ -141,6 +145,14 @@ int vfr_topk_merge_keys(const int64_t *part_keys, int G, int64_t Nq, int k, floa
 int vfr_gt_best_keys_f32(const float *own_scores, int64_t n_sel, int M, int score_stride, const uint8_t *labels, int R,
                          int label_stride, const int64_t *id_base, const int64_t *sel, int64_t Nq, int64_t *keys,
                          vfr_stream_t stream);
+
+/* a11  ground-truth labels (model/evaluate.py:59-62 with utils.get_iou, model/utils.py:78-82; main.py:161 uses >=):
+ * labels[r][q][m] = 1 iff >= 2 annotators of query q have IoU > thr[r] (strict != 0) or >= thr[r] with local moment m
+ * (utils.generate_moments order) of the query's own video of n_own[q] clips; IoU = float64 intersection / union of the
+ * inclusive clip spans.  times int32 [Nq, A, 2] (rows >= nannot[q] unused), thresholds_host: R <= 16 doubles (HOST).
+ * labels uint8 [R, Nq, Mmax], zero for m >= n(n+1)/2.                                           */
+int vfr_gt_labels_u8(const int32_t *times, const int32_t *nannot, const int32_t *n_own, int64_t Nq, int A,
+                     const double *thresholds_host, int R, int strict, int Mmax, uint8_t *labels, vfr_stream_t stream);
 
 /* ---- a1  frame normalisation: DiDeMoDataset.__getitem__ tail, get_rgb_features.py:64-69
  * THWC uint8 -> TCHW fp32, ((x/255) - mean[c]) / std[c] with the ImageNet constants (:34-35)    */

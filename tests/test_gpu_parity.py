@@ -693,3 +693,19 @@ def test_sharded_evaluate_through_kernels_equals_single(vfr, world):
     for res, d, i, v in outs:
         assert res == want and v == wv
         assert torch.equal(i, wi.cpu()) and torch.equal(d, wd.cpu())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clips", [6, "didemo", 21])
+def test_gt_labels_kernel_equals_host_table(vfr, clips):
+    """a11 on the device (vfr_gt_labels_u8) == the host table == utils.get_iou's float64 expression, ragged annotators,
+    > and >= forms, 11 thresholds (validate_epoch's sweep)."""
+    from vfr_amd import engine
+    counts = synth.clip_counts(500, clips, seed=6)
+    own, times = synth.annotations(777, counts, seed=6)
+    times = [t if i % 4 else t + [t[2], [0, 1], [1, 1]] for i, t in enumerate(times)]
+    ops = engine.HipOps()
+    for strict, thrs in ((True, [0.5, 0.7]), (False, [i / 10 for i in range(11)])):
+        want = engine.gt_label_table(times, counts[own], thrs, strict=strict)
+        got = engine.gt_labels(times, counts[own], thrs, strict, DEV, ops)
+        assert got.dtype == torch.bool and got.is_cuda and np.array_equal(got.cpu().numpy(), want)

@@ -218,8 +218,8 @@ def test_feature_store_rejects_damaged_files():
 
 
 def test_engine_exchange_helpers_on_cpu():
-    """engine.overlapped degrades to two plain calls off the GPU; _all_gather_rows falls back to the list form when the
-    process group has no all_gather_into_tensor (or refuses it) and remembers that."""
+    """engine.overlapped degrades to two plain calls off the GPU; _all_gather_rows picks its collective from what the group
+    object offers (identically on every rank) and lets a failing collective raise -- no per-rank fallback at call time."""
     from vfr_amd import engine
     assert engine.overlapped("cpu", lambda: 1, lambda: 2) == (1, 2)
     assert engine.overlapped("cuda:0", lambda: "a", lambda: "b", enable=False) == ("a", "b")
@@ -232,18 +232,67 @@ def test_engine_exchange_helpers_on_cpu():
             for g, p in enumerate(parts):
                 p.copy_(t + g)
 
-    class Refuses(ListOnly):
+    class IntoTensor(ListOnly):
         def all_gather_into_tensor(self, out, t):
-            raise RuntimeError("not supported by this backend")
+            assert out.shape == (3 * t.shape[0],) + tuple(t.shape[1:])            # concatenated form
+            for g in range(3):
+                out[g * t.shape[0]:(g + 1) * t.shape[0]].copy_(t + g)
+
+    class Fails(ListOnly):
+        def all_gather_into_tensor(self, out, t):
+            raise RuntimeError("collective failed on this rank")
 
     mine = torch.arange(6, dtype=torch.int64).reshape(2, 3)
-    old = engine._all_gather_rows.list_only
-    try:
-        for group in (ListOnly(), Refuses()):
-            engine._all_gather_rows.list_only = False
-            out = torch.empty((3, 2, 3), dtype=torch.int64)
-            engine._all_gather_rows(group, out, mine)
-            assert all(torch.equal(out[g], mine + g) for g in range(3))
-        assert engine._all_gather_rows.list_only is True and ListOnly.calls == 2
-    finally:
-        engine._all_gather_rows.list_only = old
+    for group in (ListOnly(), IntoTensor()):
+        out = torch.empty((3, 2, 3), dtype=torch.int64)
+        engine._all_gather_rows(group, out, mine)
+        assert all(torch.equal(out[g], mine + g) for g in range(3))
+    assert ListOnly.calls == 1
+    with pytest.raises(RuntimeError, match="collective failed"):
+        engine._all_gather_rows(Fails(), torch.empty((3, 2, 3), dtype=torch.int64), mine)
+    assert ListOnly.calls == 1                                   # no silent switch to another collective
+
+
+@pytest.mark.parametrize("clips", [6, "didemo", 21])
+def test_gt_label_table_vectorised_equals_get_iou_loop(clips):
+    """a11 (model/evaluate.py:59-62): the tabulated/gathered table == the reference's per-moment get_iou expression, with a
+    ragged number of annotators, both comparison forms (> for evaluate, >= for validate_epoch) and a threshold of 1.0."""
+    from vfr_amd import engine, synth
+    counts = synth.clip_counts(300, clips, seed=5)
+    own, times = synth.annotations(400, counts, seed=5)
+    times = [t if i % 3 else t + [t[1], [0, 0]] for i, t in enumerate(times)]          # 4 or 6 annotators
+    for strict, thrs in ((True, [0.5, 0.7]), (False, [0.0, 0.3, 0.5, 1.0])):
+        lab = engine.gt_label_table(times, counts[own], thrs, strict=strict)
+        assert lab.shape[:2] == (len(thrs), 400)
+        for q in range(400):
+            mom = vutils.generate_moments(int(counts[own[q]]))
+            for r, thr in enumerate(thrs):
+                iou = [vutils.get_iou(times[q], s, e) for s, e in mom]
+                want = [int(((i > thr) if strict else (i >= thr)).sum() >= 2) for i in iou]
+                assert lab[r, q, :len(mom)].astype(int).tolist() == want
+                assert not lab[r, q, len(mom):].any()
+    t, na = engine.pack_times(times)
+    assert t.shape == (400, 6, 2) and na.tolist() == [6 if i % 3 == 0 else 4 for i in range(400)]
+    assert engine.gt_label_table([], np.zeros(0, int), [0.5]).shape == (1, 0, 0)
+
+
+@pytest.mark.parametrize("tag,clips", [("n6", 6), ("ragged", "didemo")])
+def test_evaluate_chance_baseline_matches_reference(tag, clips, capsys):
+    """evaluate(model_types=['model', 'chance']) under np.random.seed(123) == the reference's dict (fixture G8): one
+    permutation per query shared by both IoU thresholds (evaluate.py:68-72); 130 queries also cross the preliminary print."""
+    ref = json.load(open(Path(__file__).parent / "golden" / "g8_chance.json"))[tag]
+    p = problem(40, 130, clips, feat_dim=256, seed=88)
+    ds = MemoryDataset(p["seg"], p["ctx"], p["counts"], p["tokens"], p["own"], p["times"])
+    model = make_model(p["sd"], feat_dim=256)
+    vi, li = ds.iterators()
+    np.random.seed(123)
+    got = vevaluate.evaluate(model, vi, li, ds.annotations, "cpu", model_types=["model", "chance"])
+    assert set(got) == set(ref)
+    for key in ref:
+        for name in ref[key]:
+            assert got[key][name] == pytest.approx(ref[key][name], abs=1e-9), (key, name)
+    assert capsys.readouterr().out.count("chance, IoU=0.5") == 1                     # printed once, at query 101 (li = 100)
+    vi, li = ds.iterators()
+    np.random.seed(123)
+    vevaluate.evaluate(model, vi, li, ds.annotations, "cpu", model_types=["model", "chance"], preliminary=129)
+    assert capsys.readouterr().out.count("chance, IoU=0.5") == 1                     # len == m * preliminary + 1 still prints

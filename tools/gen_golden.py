@@ -9,7 +9,8 @@ OUTPUTS plus the recipe parameters; tests regenerate the inputs from the same se
     python tools/gen_golden.py            # writes tests/golden/*.npz, tokens.json
 
 Fixtures:  G1 encoders, G2 scoring + both evaluate() dicts (n=6, n=21, ragged 5/6),
-G3 generate_moments / get_iou, G4 load_video_features pooling, G5 tokeniser + WordIndexer.
+G3 generate_moments / get_iou, G4 load_video_features pooling, G5 tokeniser + WordIndexer, G6 validate_epoch,
+G7 ranking loss, G8 evaluate() with the 'chance' baseline.
 """
 import json
 import random
@@ -297,6 +298,30 @@ def g7_ranking_loss():
     print("G7", {k: (v.shape if hasattr(v, "shape") and v.shape else v) for k, v in out.items() if k.startswith(("loss", "n_"))})
 
 
+def g8_chance(nv=40, nq=130, feat_dim=256):
+    """evaluate.evaluate(model_types=['model', 'chance']) under np.random.seed(123): the chance permutation is drawn ONCE
+    per query and shared by the IoU thresholds (evaluate.py:68-72); nq = 130 also crosses the `preliminary` print."""
+    out = {}
+    for tag, clips in (("n6", 6), ("ragged", "didemo")):
+        counts = synth.clip_counts(nv, clips, seed=88)
+        off = synth.clip_offsets(counts)
+        seg, ctx = synth.video_features(counts, feat_dim, seed=88)
+        tokens = synth.query_tokens(nq, seed=88)
+        own, times = synth.annotations(nq, counts, seed=88)
+        sd = synth.model_weights(feat_dim, seed=88)
+        m = ref_model(sd, feat_dim)
+        ds, videos, annots = make_dataset(seg, ctx, off, tokens, own, times)
+        vi = DataLoader(ds, shuffle=False, collate_fn=ref_data.validate_collate,
+                        batch_sampler=ref_data.VideoBatchSampler(videos, ds.num_segments_info))
+        li = DataLoader(ds, shuffle=False, collate_fn=ref_data.validate_collate,
+                        batch_sampler=ref_data.LanguageBatchSampler(annots, ds.num_segments_info))
+        np.random.seed(123)
+        out[tag] = ref_evaluate.evaluate(m, vi, li, annots, "cpu", model_types=["model", "chance"])
+    json.dump({k: {kk: {n: float(x) for n, x in vv.items()} for kk, vv in v.items()} for k, v in out.items()},
+              open(OUT / "g8_chance.json", "w"), indent=1)
+    print("G8", out)
+
+
 if __name__ == "__main__":
     g3_moments_iou()
     g5_tokens()
@@ -307,3 +332,4 @@ if __name__ == "__main__":
     g2_scoring("n21", 21)
     g6_validate_epoch()
     g7_ranking_loss()
+    g8_chance()

@@ -46,6 +46,7 @@ SIGNATURES = {
     "vfr_topk_pack_keys": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "vfr_topk_merge_keys": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "vfr_gt_best_keys_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "vfr_gt_labels_u8": (_i32, [_vp, _vp, _vp, _i64, _i32, ctypes.POINTER(ctypes.c_double), _i32, _i32, _i32, _vp, _vp]),
     "vfr_ranking_loss_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "vfr_ranking_loss_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _sz, _vp]),
     "vfr_ranking_loss_grad_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp,
@@ -361,6 +362,18 @@ def gt_best_keys(own_scores: torch.Tensor, labels: torch.Tensor, id_base: torch.
     _check(lib().vfr_gt_best_keys_f32(sc.data_ptr(), n_sel, min(sc.shape[1], Ml), sc.shape[1], lab.data_ptr(), R, Ml,
                                       base.data_ptr(), sel.data_ptr(), Nq, keys.data_ptr(), _stream()), "vfr_gt_best_keys_f32")
     return keys
+
+
+def gt_labels(times: torch.Tensor, nannot: torch.Tensor, n_own: torch.Tensor, thresholds, strict: bool, Mmax: int):
+    """a11 on the device: times int32 [Nq, A, 2], nannot / n_own int32 [Nq] -> labels bool [R, Nq, Mmax]."""
+    t, na, no = _dev(times, torch.int32, "times"), _dev(nannot, torch.int32, "nannot"), _dev(n_own, torch.int32, "n_own")
+    Nq, A = t.shape[0], t.shape[1]
+    R = len(thresholds)
+    thr = (ctypes.c_double * R)(*[float(x) for x in thresholds])
+    lab = torch.empty((R, Nq, Mmax), dtype=torch.uint8, device=t.device)
+    _check(lib().vfr_gt_labels_u8(t.data_ptr(), na.data_ptr(), no.data_ptr(), Nq, A, thr, R, int(bool(strict)), Mmax,
+                                  lab.data_ptr(), _stream()), "vfr_gt_labels_u8")
+    return lab.view(torch.bool)
 
 
 def frames_normalize(frames_thwc: torch.Tensor) -> torch.Tensor:

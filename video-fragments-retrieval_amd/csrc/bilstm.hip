@@ -11,7 +11,7 @@
 //
 // 352.4 MFLOP per query; the recurrent GEMM [B,H]x[H,4H] is the MFMA-bound part.
 #include "vfr_common.h"
-#include "vfr_math.cuh"
+#include "vfr_math.h"
 
 namespace vfr {
 

@@ -9,7 +9,7 @@
 // Used by: visual MLP (model/models.py:21-26), BiLSTM input/recurrent projections and lang_fc
 // (model/models.py:40-47), BERT-branch Linear (:31), VGG fc6/fc7 (get_rgb_features.py:126).
 #include "vfr_common.h"
-#include "vfr_math.cuh"
+#include "vfr_math.h"
 
 namespace vfr {
 

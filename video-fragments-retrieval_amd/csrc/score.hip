@@ -4,24 +4,20 @@
 //   score(s,e) = (dist[s] + ... + dist[e]) / (e-s+1)   index_select().mean()
 //   ranking    = ascending (score, global moment id)    np.argsort, made deterministic
 //
-// Mapping onto gfx950 (exact fp32, VALU-bound: the direct-difference form is not a GEMM):
-//   * thread = query.  A wave owns 64 queries; each lane keeps its query embedding (D = 100 floats)
-//     in VGPRs for the whole kernel -- the per-query embedding tile is register-resident.
-//   * the clip embedding being scored is the same for all 64 lanes, so V streams through the scalar
-//     cache into SGPRs (s_load_dwordxN) and feeds the VALU as a scalar operand: every V byte is read
-//     once per wave, coalesced by construction, no LDS staging and no bank conflicts.
-//   * 4 clips are scored at a time (4 independent fma chains per lane) for ILP; the clip distances of
-//     the current video go to a per-wave LDS column (ds[c][lane], conflict-free), from which each lane
-//     walks the moment triangle sequentially (the canonical summation order).
-//   * selection: each lane filters against its own threshold (the k-th best key seen so far, shared
-//     between all waves working on the same query through a global atomicMin) and appends survivors
-//     to its candidate buffer; when a buffer fills, the wave sorts it cooperatively with a register
-//     bitonic network (64 lanes x KPL keys, cross-lane exchanges by wave shuffles) and keeps the k
-//     best.  A wave never synchronises with another wave.
-//   * keys are (fp32 bits of score << 32 | moment id): scores are >= 0 so unsigned order == the
-//     (score, id) lexicographic order, one 64-bit compare per test.
+// Mapping onto gfx950.  Three families of kernels live here:
+//   * score_kernel (generic shapes, any D, up to 64 clips): thread = query, V read per lane through L1, the clip distances
+//     of the current video in a per-wave LDS column, candidates compacted by a cooperative register bitonic sort.
+//   * score_fast_kernel (D = 100, <= 6 or exactly <= 21 clips): exact fp32 on the VALU -- the direct-difference form
+//     ((v - q) + eps)^2 is not a GEMM.  thread = query with the query embedding in 50 float2 VGPR pairs; the clip rows being
+//     scored are wave-uniform, staged per wave into LDS with coalesced 16-byte loads and read back as broadcast ds_read_b128
+//     (no barrier, a wave never waits for another); branch-free moment triangle on register sums with thresholds as integer
+//     bounds on the fp32 bits of the SUM (no division, no key on the common path).  Details at the kernel.
+//   * score_mfma.h (included below): the MFMA pre-filter -- approximate distances from the GEMM form on the matrix cores,
+//     three-way threshold tests with a rigorous error margin, exact re-scoring of whatever the margin cannot decide.
+//   * keys are (fp32 bits of score << 32 | moment id): scores are >= 0 so unsigned order == the (score, id) lexicographic
+//     order, one 64-bit compare per test.
 #include "vfr_common.h"
-#include "vfr_math.cuh"
+#include "vfr_math.h"
 
 namespace vfr {
 
@@ -975,6 +971,44 @@ __global__ __launch_bounds__(256) void gt_best_keys_kernel(const float *__restri
     }
 }
 
+// a11 (model/evaluate.py:59-62, utils.get_iou model/utils.py:78-82): labels[r][q][m] = 1 iff at least two annotators have
+// IoU > (or >=) thr[r] with local moment m of the query's own video.  One thread per (query, moment); the IoU is the
+// reference's float64 intersection / union (IEEE division: the same bits as numpy's).
+constexpr int MAX_LABEL_THR = 16;
+struct LabelThr { double t[MAX_LABEL_THR]; };
+__global__ __launch_bounds__(256) void gt_labels_kernel(const int32_t *__restrict__ times, const int32_t *__restrict__ nannot,
+                                                        const int32_t *__restrict__ n_own, int64_t Nq, int A, int R,
+                                                        LabelThr thr, int strict, int Mmax, uint8_t *__restrict__ labels)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Nq * Mmax) return;
+    const int64_t q = i / Mmax;
+    const int m = (int)(i - q * Mmax), n = n_own[q];
+    int s = m, e = m;                                     // generate_moments order: (j, j) first, then combinations
+    bool real = m < n * (n + 1) / 2;
+    if (real && m >= n) {
+        int rest = m - n;
+        s = 0;
+        while (rest >= n - 1 - s) { rest -= n - 1 - s; ++s; }
+        e = s + 1 + rest;
+    }
+    int cnt[MAX_LABEL_THR];
+#pragma unroll
+    for (int r = 0; r < MAX_LABEL_THR; ++r) cnt[r] = 0;
+    const int na = nannot[q];
+    for (int a = 0; a < na && real; ++a) {
+        const int ts = times[(q * A + a) * 2], te = times[(q * A + a) * 2 + 1];
+        const int inter = max(min(te, e) + 1 - max(ts, s), 0), uni = max(te, e) + 1 - min(ts, s);
+        const double iou = (double)inter / (double)uni;
+#pragma unroll
+        for (int r = 0; r < MAX_LABEL_THR; ++r)
+            if (r < R) cnt[r] += (strict ? iou > thr.t[r] : iou >= thr.t[r]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < MAX_LABEL_THR; ++r)
+        if (r < R) labels[((int64_t)r * Nq + q) * Mmax + m] = cnt[r] >= 2 ? 1 : 0;
+}
+
 // each query against its own video (evaluate_single.py:48-53).  One WAVE per query: lane c runs clip c's k-ascending
 // distance chain (the clips of a video are independent chains), the distances go through LDS, then lane s walks the spans
 // (s, s), (s, s+1), ... keeping the left-to-right running sum of the oracle.  (Thread-per-query left the chip to 79 waves
@@ -1345,6 +1379,22 @@ int vfr_gt_best_keys_f32(const float *own_scores, int64_t n_sel, int M, int scor
     hipLaunchKernelGGL(vfr::gt_best_keys_kernel, dim3((unsigned)vfr::cdiv(n_sel, 4)), dim3(256), 0, vfr::as_stream(stream),
                        own_scores, n_sel, M, score_stride, labels, R, label_stride, id_base, sel, Nq, keys);
     VFR_CHECK_LAUNCH("gt_best_keys_kernel");
+    return VFR_OK;
+}
+
+int vfr_gt_labels_u8(const int32_t *times, const int32_t *nannot, const int32_t *n_own, int64_t Nq, int A,
+                     const double *thresholds_host, int R, int strict, int Mmax, uint8_t *labels, vfr_stream_t stream)
+{
+    VFR_REQUIRE(Nq >= 0 && A >= 0 && Mmax >= 0 && R > 0 && thresholds_host, VFR_EINVAL, "vfr_gt_labels_u8: bad argument");
+    VFR_REQUIRE(R <= vfr::MAX_LABEL_THR, VFR_EUNSUPPORTED, "vfr_gt_labels_u8: R=%d > %d thresholds", R, vfr::MAX_LABEL_THR);
+    if (Nq == 0 || Mmax == 0) return VFR_OK;
+    VFR_REQUIRE(times && nannot && n_own && labels, VFR_EINVAL, "vfr_gt_labels_u8: null pointer");
+    vfr::LabelThr t{};
+    for (int r = 0; r < R; ++r) t.t[r] = thresholds_host[r];
+    vfr::ProfScope prof(vfr::SITE_EXCHANGE, vfr::as_stream(stream));
+    hipLaunchKernelGGL(vfr::gt_labels_kernel, dim3((unsigned)vfr::cdiv(Nq * Mmax, 256)), dim3(256), 0, vfr::as_stream(stream),
+                       times, nannot, n_own, Nq, A, R, t, strict, Mmax, labels);
+    VFR_CHECK_LAUNCH("gt_labels_kernel");
     return VFR_OK;
 }
 

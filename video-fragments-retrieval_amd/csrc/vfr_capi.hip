@@ -1,7 +1,8 @@
 // Error plumbing, options and the elementwise math probe of libvfr.so.
 #include "vfr_common.h"
-#include "vfr_math.cuh"
+#include "vfr_math.h"
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -9,22 +10,28 @@
 namespace vfr {
 
 static thread_local char g_err[512] = "";
-static int g_opt_gemm = 1;
-static int g_opt_profile = 0;
-static int g_opt_score_fast = 1;
-static int g_opt_score_split = 0;
-static int g_opt_gemm_small = 0;       // small dense GEMMs: 0 = 32-row tiles, 64 = 64-row tiles (cross-check)
-static int g_opt_lstm_xcd = 1;         // 1: XCD-aware workgroup order of the fused LSTM step; 0: launch order (cross-check)
-static int g_opt_lstm_skip0 = 1;       // 1: the first LSTM step skips its recurrent segment (h_0 = 0); 0: runs it (cross-check)
-static int g_opt_score_tasks = 0;      // > 0: wave-tasks the scorer's plan aims for (experiment; 0 = automatic)
-static int g_opt_score_pre_b = 0;      // > 0: videos in ladder stage B (experiment; 0 = Nv/8 capped at 1024)
-static int g_opt_gemm_pp = 0;          // 1: ping-pong schedule (512-thread workgroups, two tile groups) for the large MFMA GEMMs (experiment)
-static int g_opt_lstm_tile = 0;        // 0: by grid size, 1: 64-row tiles, 2: 128-row tiles (fused LSTM step)
+static std::atomic<int> g_opt_gemm{1};
+static std::atomic<int> g_opt_profile{0};
+static std::atomic<int> g_opt_score_fast{1};
+static std::atomic<int> g_opt_score_split{0};
+static std::atomic<int> g_opt_gemm_small{0};       // small dense GEMMs: 0 = 32-row tiles, 64 = 64-row tiles (cross-check)
+static std::atomic<int> g_opt_lstm_xcd{1};         // 1: XCD-aware workgroup order of the fused LSTM step; 0: launch order (cross-check)
+static std::atomic<int> g_opt_lstm_skip0{1};       // 1: the first LSTM step skips its recurrent segment (h_0 = 0); 0: runs it (cross-check)
+static std::atomic<int> g_opt_score_tasks{0};      // > 0: wave-tasks the scorer's plan aims for (experiment; 0 = automatic)
+static std::atomic<int> g_opt_score_pre_b{0};      // > 0: videos in ladder stage B (experiment; 0 = Nv/16 capped at 640)
+static std::atomic<int> g_opt_gemm_pp{0};          // 1: ping-pong schedule (512-thread workgroups, two tile groups) for the large MFMA GEMMs (experiment)
+static std::atomic<int> g_opt_lstm_tile{0};        // 0: by grid size, 1: 64-row tiles, 2: 128-row tiles (fused LSTM step)
+
+struct Opt { const char *name; std::atomic<int> *v; };
+static const Opt g_opts[] = {
+    {"gemm", &g_opt_gemm}, {"profile", &g_opt_profile}, {"score_fast", &g_opt_score_fast}, {"score_split", &g_opt_score_split},
+    {"score_pre_b", &g_opt_score_pre_b}, {"score_tasks", &g_opt_score_tasks}, {"lstm_skip0", &g_opt_lstm_skip0},
+    {"lstm_xcd", &g_opt_lstm_xcd}, {"gemm_small", &g_opt_gemm_small}, {"lstm_tile", &g_opt_lstm_tile}, {"gemm_pp", &g_opt_gemm_pp},
+};
 
 struct ProfPair { int site; hipEvent_t a, b; };
 static std::vector<ProfPair> g_pairs;          // recorded, not yet read
 static std::vector<hipEvent_t> g_free;         // recycled events
-static hipEvent_t g_open[SITE_COUNT];
 static double g_total_ms[SITE_COUNT];
 static long long g_launches[SITE_COUNT];
 static std::mutex g_prof_mu;
@@ -37,19 +44,23 @@ static hipEvent_t take_event()
     (void)hipEventCreate(&e);
     return e;
 }
-void prof_begin(int site, hipStream_t st)
+// The begin event travels in the caller's ProfScope (not in a per-site global), so any number of host threads can bracket
+// launches of the same site at once; only the event pool and the pair list are shared, under the mutex.
+hipEvent_t prof_begin(hipStream_t st)
 {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    hipEvent_t e = take_event();
-    (void)hipEventRecord(e, st);
-    g_open[site] = e;
+    hipEvent_t e;
+    { std::lock_guard<std::mutex> lk(g_prof_mu); e = take_event(); }
+    if (e) (void)hipEventRecord(e, st);
+    return e;
 }
-void prof_end(int site, hipStream_t st)
+void prof_end(int site, hipEvent_t begin, hipStream_t st)
 {
+    hipEvent_t e;
+    { std::lock_guard<std::mutex> lk(g_prof_mu); e = take_event(); }
+    if (e) (void)hipEventRecord(e, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    hipEvent_t e = take_event();
-    (void)hipEventRecord(e, st);
-    g_pairs.push_back({site, g_open[site], e});
+    if (begin && e) g_pairs.push_back({site, begin, e});
+    else { if (begin) g_free.push_back(begin); if (e) g_free.push_back(e); }
 }
 
 char *error_buffer() { return g_err; }
@@ -98,32 +109,14 @@ const char *vfr_last_error(void) { return vfr::g_err; }
 
 int vfr_set_option(const char *name, int value)
 {
-    if (name && !strcmp(name, "gemm")) { vfr::g_opt_gemm = value; return VFR_OK; }
-    if (name && !strcmp(name, "profile")) { vfr::g_opt_profile = value; return VFR_OK; }
-    if (name && !strcmp(name, "score_fast")) { vfr::g_opt_score_fast = value; return VFR_OK; }
-    if (name && !strcmp(name, "score_split")) { vfr::g_opt_score_split = value; return VFR_OK; }
-    if (name && !strcmp(name, "score_pre_b")) { vfr::g_opt_score_pre_b = value; return VFR_OK; }
-    if (name && !strcmp(name, "score_tasks")) { vfr::g_opt_score_tasks = value; return VFR_OK; }
-    if (name && !strcmp(name, "lstm_skip0")) { vfr::g_opt_lstm_skip0 = value; return VFR_OK; }
-    if (name && !strcmp(name, "lstm_xcd")) { vfr::g_opt_lstm_xcd = value; return VFR_OK; }
-    if (name && !strcmp(name, "gemm_small")) { vfr::g_opt_gemm_small = value; return VFR_OK; }
-    if (name && !strcmp(name, "lstm_tile")) { vfr::g_opt_lstm_tile = value; return VFR_OK; }
-    if (name && !strcmp(name, "gemm_pp")) { vfr::g_opt_gemm_pp = value; return VFR_OK; }
+    for (const auto &o : vfr::g_opts)
+        if (name && !strcmp(name, o.name)) { o.v->store(value); return VFR_OK; }
     return vfr::fail(VFR_EINVAL, "vfr_set_option: unknown option '%s'", name ? name : "(null)");
 }
 int vfr_get_option(const char *name)
 {
-    if (name && !strcmp(name, "gemm")) return vfr::g_opt_gemm;
-    if (name && !strcmp(name, "profile")) return vfr::g_opt_profile;
-    if (name && !strcmp(name, "score_fast")) return vfr::g_opt_score_fast;
-    if (name && !strcmp(name, "score_split")) return vfr::g_opt_score_split;
-    if (name && !strcmp(name, "score_pre_b")) return vfr::g_opt_score_pre_b;
-    if (name && !strcmp(name, "score_tasks")) return vfr::g_opt_score_tasks;
-    if (name && !strcmp(name, "lstm_skip0")) return vfr::g_opt_lstm_skip0;
-    if (name && !strcmp(name, "lstm_xcd")) return vfr::g_opt_lstm_xcd;
-    if (name && !strcmp(name, "gemm_small")) return vfr::g_opt_gemm_small;
-    if (name && !strcmp(name, "lstm_tile")) return vfr::g_opt_lstm_tile;
-    if (name && !strcmp(name, "gemm_pp")) return vfr::g_opt_gemm_pp;
+    for (const auto &o : vfr::g_opts)
+        if (name && !strcmp(name, o.name)) return o.v->load();
     return vfr::fail(VFR_EINVAL, "vfr_get_option: unknown option '%s'", name ? name : "(null)");
 }
 
@@ -142,15 +135,23 @@ int vfr_profile_read(int site, double *total_ms, int64_t *launches, int reset)
 {
     VFR_REQUIRE(site >= 0 && site < vfr::SITE_COUNT, VFR_EINVAL, "vfr_profile_read: bad site %d", site);
     std::lock_guard<std::mutex> lk(vfr::g_prof_mu);
-    for (auto &p : vfr::g_pairs) {            // fold every completed pair (caller synchronised the device)
+    // fold every completed pair; a pair whose events have not finished (the caller did not synchronise that stream) stays
+    // queued for the next read -- its events are never recycled while they may still be pending
+    std::vector<vfr::ProfPair> pending;
+    int failed = 0;
+    for (auto &p : vfr::g_pairs) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { vfr::g_total_ms[p.site] += ms; vfr::g_launches[p.site] += 1; }
+        const hipError_t e = hipEventElapsedTime(&ms, p.a, p.b);
+        if (e == hipSuccess) { vfr::g_total_ms[p.site] += ms; vfr::g_launches[p.site] += 1; }
+        else if (e == hipErrorNotReady) { (void)hipGetLastError(); pending.push_back(p); continue; }
+        else { (void)hipGetLastError(); ++failed; }
         vfr::g_free.push_back(p.a); vfr::g_free.push_back(p.b);
     }
-    vfr::g_pairs.clear();
+    vfr::g_pairs.swap(pending);
     if (total_ms) *total_ms = vfr::g_total_ms[site];
     if (launches) *launches = vfr::g_launches[site];
     if (reset) for (int i = 0; i < vfr::SITE_COUNT; ++i) { vfr::g_total_ms[i] = 0; vfr::g_launches[i] = 0; }
+    if (failed) return vfr::fail(VFR_EHIP, "vfr_profile_read: %d event pair(s) could not be timed and were dropped", failed);
     return VFR_OK;
 }
 

@@ -39,12 +39,14 @@ enum Site : int {
     SITE_COUNT
 };
 bool profiling();
-void prof_begin(int site, hipStream_t st);
-void prof_end(int site, hipStream_t st);
-struct ProfScope {
-    int site; hipStream_t st; bool on;
-    ProfScope(int s, hipStream_t t) : site(s), st(t), on(s != SITE_NONE && profiling()) { if (on) prof_begin(site, st); }
-    ~ProfScope() { if (on) prof_end(site, st); }
+hipEvent_t prof_begin(hipStream_t st);
+void prof_end(int site, hipEvent_t begin, hipStream_t st);
+struct ProfScope {                       // owns its begin event: re-entrant across host threads, sites and streams
+    int site; hipStream_t st; bool on; hipEvent_t begin;
+    ProfScope(int s, hipStream_t t) : site(s), st(t), on(s != SITE_NONE && profiling()), begin(nullptr) { if (on) begin = prof_begin(st); }
+    ~ProfScope() { if (on) prof_end(site, begin, st); }
+    ProfScope(const ProfScope &) = delete;
+    ProfScope &operator=(const ProfScope &) = delete;
 };
 
 #define VFR_REQUIRE(cond, code, ...)                         \

@@ -1,4 +1,4 @@
-"""Sibling-import shim: ``cd video-fragments-retrieval_amd/dropin && python <reference>/model/main.py`` (or put this
+"""Sibling-import shim: put this
 directory first on sys.path) makes the reference's ``import utils`` resolve to the MI355X implementation."""
 import sys as _sys
 from pathlib import Path as _Path

@@ -64,6 +64,16 @@ class HipOps:
     def gt_best_keys(self, own_scores, labels, id_base, sel, Nq):
         return self.v.gt_best_keys(own_scores, labels, id_base, sel, Nq)
 
+    def gt_labels(self, packed_times, n_own, thresholds, strict, device, Mmax=None):
+        """``packed_times`` / ``n_own``: host arrays (uploaded here) or tensors already resident on the device (then pass
+        ``Mmax`` = moments of the longest own video, so no device value has to be read back)."""
+        t, na = packed_times
+        as_dev = lambda x: x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(device)
+        if Mmax is None:
+            nmax = int(n_own.max()) if len(n_own) else 0
+            Mmax = nmax * (nmax + 1) // 2
+        return self.v.gt_labels(as_dev(t), as_dev(na), as_dev(n_own), thresholds, strict, Mmax)
+
 
 def shard_range(num_videos: int, rank: int, world: int):
     """Contiguous, balanced split of the video iteration order."""
@@ -78,18 +88,16 @@ def _dist():
 def _all_gather_rows(dist, out, mine):
     """out[g] <- rank g's ``mine`` for a contiguous ``out [world, *mine.shape]``: ONE collective straight into the buffer
     (``all_gather_into_tensor``; the list form makes the RCCL backend gather into a scratch tensor and copy the parts out).
-    Process groups without it (or stand-ins in tests) take the list form."""
+    Which form is used is decided from what the ``dist`` object offers -- the same on every rank, never from an exception
+    at call time (a rank that fell back alone would issue a different collective than its peers and hang them): the list
+    form is only for the thread-rank / provider stand-ins of the tests, which have no ``all_gather_into_tensor``."""
     fn = getattr(dist, "all_gather_into_tensor", None)
-    if fn is not None and not _all_gather_rows.list_only:
-        try:
-            fn(out, mine)
-            return
-        except (RuntimeError, NotImplementedError):
-            _all_gather_rows.list_only = True
-    dist.all_gather([out[g] for g in range(out.shape[0])], mine)
-
-
-_all_gather_rows.list_only = False
+    if fn is not None:
+        # concatenated form (rank g's rows at [g * rows, (g + 1) * rows)): the same memory as out[g], and the shape both
+        # the RCCL and the gloo process groups accept
+        fn(out.view((out.shape[0] * mine.shape[0],) + tuple(mine.shape[1:])) if mine.dim() >= 1 else out, mine)
+    else:
+        dist.all_gather([out[g] for g in range(out.shape[0])], mine)
 
 
 @dataclass
@@ -236,23 +244,62 @@ def encode_queries(model, tokens, device, ops=None, rank=0, world=1):
     return parts.reshape(world * per, -1)[:Nq].contiguous()
 
 
+def pack_times(times):
+    """Annotator spans of a query batch -> (int32 [Nq, A, 2] zero padded, int32 [Nq] annotator counts).  Host; the only
+    per-query Python work of a11 (flattening the nested lists), ~1.5 ms for 5000 queries."""
+    import itertools
+    nq = len(times)
+    na = np.fromiter((len(t) for t in times), dtype=np.int32, count=nq)
+    amax = int(na.max()) if nq else 0
+    flat = np.fromiter(itertools.chain.from_iterable(itertools.chain.from_iterable(times)), dtype=np.int32,
+                       count=2 * int(na.sum()))
+    if nq and int(na.min()) == amax:
+        return flat.reshape(nq, amax, 2), na
+    out = np.zeros((nq, amax, 2), np.int32)
+    mask = np.arange(amax)[None, :] < na[:, None]
+    out[mask] = flat.reshape(-1, 2)
+    return out, na
+
+
 def gt_label_table(times, counts_own, thresholds, strict=True):
     """labels[r, q, m] = 1 iff >= 2 annotators have IoU (>, or >= when not strict) thresholds[r] with local
-    moment m of the query's own video (``model/evaluate.py:59-62``; ``main.py:161`` uses >=).  Host numpy."""
-    nmax = int(max(counts_own)) if len(counts_own) else 0
+    moment m of the query's own video (``model/evaluate.py:59-62``; ``main.py:161`` uses >=).  Host numpy, vectorised
+    over the queries (one pass per distinct clip count): float64 ``intersection / union`` like ``utils.get_iou``."""
+    counts_own = np.asarray(counts_own, np.int64)
+    nmax = int(counts_own.max()) if len(counts_own) else 0
     Mmax = nmax * (nmax + 1) // 2
-    labels = np.zeros((len(thresholds), len(times), Mmax), dtype=bool)
-    spans = {n: np.asarray(generate_moments(n), np.int64).reshape(-1, 2) for n in set(int(c) for c in counts_own)}
-    for q, (t, n) in enumerate(zip(times, counts_own)):
-        mom = spans[int(n)]
-        t = np.asarray(t)
-        inter = np.maximum(np.minimum(t[None, :, 1], mom[:, None, 1]) + 1 - np.maximum(t[None, :, 0], mom[:, None, 0]), 0)
-        union = np.maximum(t[None, :, 1], mom[:, None, 1]) + 1 - np.minimum(t[None, :, 0], mom[:, None, 0])
-        iou = inter / union                                                   # [M, annotators], float64 like get_iou
+    t, na = times if isinstance(times, tuple) else pack_times(times)
+    labels = np.zeros((len(thresholds), len(na), Mmax), dtype=bool)
+    if not len(na):
+        return labels
+    valid = np.arange(t.shape[1])[None, :, None] < na[:, None, None]              # [Nq, A, 1]
+    for n in np.unique(counts_own):
+        q = np.nonzero(counts_own == n)[0]
+        mom = np.asarray(generate_moments(int(n)), np.int64).reshape(-1, 2)
+        tq = t[q].astype(np.int64)
+        # the IoU of an annotator span with a moment depends only on the two spans: tabulate it for every span (ts, te) in
+        # [0, T)^2 once per clip count, then every query just gathers its annotators' rows
+        T = max(int(n), int(tq.max()) + 1 if tq.size else 0)
+        lo = int(tq.min()) if tq.size else 0
+        ts, te = np.meshgrid(np.arange(lo, T), np.arange(lo, T), indexing="ij")
+        ts, te = ts[:, :, None], te[:, :, None]
+        s, e = mom[None, None, :, 0], mom[None, None, :, 1]
+        inter = np.maximum(np.minimum(te, e) + 1 - np.maximum(ts, s), 0)
+        union = np.maximum(te, e) + 1 - np.minimum(ts, s)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iou = (inter / union).reshape(-1, len(mom))                           # [(T-lo)^2, M] float64, like get_iou
+        ids = (tq[:, :, 0] - lo) * (T - lo) + (tq[:, :, 1] - lo)                  # [nq_n, A]
         for r, thr in enumerate(thresholds):
-            hit = (iou > thr) if strict else (iou >= thr)
+            hit = ((iou > thr) if strict else (iou >= thr))[ids] & valid[q]       # [nq_n, A, M]
             labels[r, q, :len(mom)] = hit.sum(axis=1) >= 2
     return labels
+
+
+def gt_labels(times, counts_own, thresholds, strict, device, ops):
+    """a11 for a query batch on ``device``: the label table [R, Nq, Mmax] (bool), built by the provider -- one kernel
+    launch on a ROCm device (``vfr_gt_labels_u8``), the vectorised numpy table on the CPU device."""
+    packed = times if isinstance(times, tuple) else pack_times(times)
+    return ops.gt_labels(packed, np.asarray(counts_own, np.int32), list(thresholds), strict, device)
 
 
 def _pack_key(dist_t: torch.Tensor, idx_t: torch.Tensor) -> torch.Tensor:
@@ -268,30 +315,51 @@ def _unpack_key(key: torch.Tensor):
 
 @dataclass
 class QueryGT:
-    """Ground truth of a query batch, resident on the device (built once per batch, outside any timed loop)."""
+    """Ground truth of a query batch on the device: the index part (which queries' own videos live in this shard, where
+    their moments start -- bookkeeping of the batch, ``gt_index``) and the a11 label table of those queries."""
     num_thresholds: int
     num_queries: int
     sel: object = None           # int64 [n_sel] positions of the queries whose own video lives in this shard
     own_local: object = None     # int32 [n_sel] shard-local video index
     labels: object = None        # bool  [R, n_sel, Mloc]
     base: object = None          # int64 [n_sel] global id of the own video's first moment
+    all_local: bool = False      # sel == every query, in order (single shard): the label table is used as it is
+    Mloc: int = 0
 
 
-def prepare_gt(shard: CorpusShard, own_global, labels) -> QueryGT:
+def gt_index(shard: CorpusShard, own_global) -> QueryGT:
+    """The label-free part of ``prepare_gt``: depends only on which video each query belongs to."""
     own = np.asarray(own_global, np.int64)
-    R, Nq, Mmax = labels.shape
-    gt = QueryGT(R, Nq)
+    gt = QueryGT(0, len(own))
     local = (own >= shard.lo) & (own < shard.hi)
-    if local.any() and Mmax > 0:
+    if local.any():
         sel = np.nonzero(local)[0]
         nloc = shard.counts_all[shard.lo:shard.hi]
         nmax = int(nloc.max()) if len(nloc) else 0
-        Mloc = min(Mmax, nmax * (nmax + 1) // 2)
         dev = shard.device
+        gt.Mloc = nmax * (nmax + 1) // 2
+        gt.all_local = len(sel) == len(own)
         gt.sel = torch.from_numpy(sel).to(dev)
         gt.own_local = torch.from_numpy((own[sel] - shard.lo).astype(np.int32)).to(dev)
-        gt.labels = torch.from_numpy(np.ascontiguousarray(labels[:, sel, :Mloc])).to(dev)
         gt.base = torch.from_numpy(shard.mom_off_all[own[sel]]).to(dev)
+    return gt
+
+
+def prepare_gt(shard: CorpusShard, own_global, labels, index: QueryGT | None = None) -> QueryGT:
+    """``labels`` [R, Nq, Mmax]: the host table (``gt_label_table``) or the device one (``gt_labels``)."""
+    idx = index if index is not None else gt_index(shard, own_global)
+    R, Nq, Mmax = labels.shape
+    gt = QueryGT(R, Nq, idx.sel, idx.own_local, None, idx.base, idx.all_local, idx.Mloc)
+    if idx.sel is not None and Mmax > 0:
+        Mloc = min(Mmax, idx.Mloc)
+        if isinstance(labels, torch.Tensor):
+            lab = labels if labels.device == shard.device else labels.to(shard.device)
+            gt.labels = lab if (idx.all_local and Mloc == Mmax) else lab[:, idx.sel, :Mloc].contiguous()
+        else:
+            sel = idx.sel.cpu().numpy()
+            gt.labels = torch.from_numpy(np.ascontiguousarray(labels[:, sel, :Mloc])).to(shard.device)
+    else:
+        gt.sel = None
     return gt
 
 
@@ -535,6 +603,9 @@ class TorchCpuOps:
             od = torch.where(srt == KEY_INF, torch.full_like(od, float("inf")), od)
             oi = torch.where(srt == KEY_INF, torch.full_like(oi, -1), oi)
         return od, oi, (srt if want_keys else None)
+
+    def gt_labels(self, packed_times, n_own, thresholds, strict, device, Mmax=None):
+        return torch.from_numpy(gt_label_table(packed_times, np.asarray(n_own), thresholds, strict))
 
     def gt_best_keys(self, own_scores, labels, id_base, sel, Nq):
         R = labels.shape[0]

@@ -85,27 +85,36 @@ def evaluate(model, video_iterator, lang_iterator, annotations, device, prelimin
     video_index = {name: i for i, name in enumerate(names)}
     own = np.asarray([video_index[v] for v in q_videos], np.int64)
     times = [annotations[a]["times"] for a in annot_ids]
-    labels = engine.gt_label_table(times, shard.counts_all[own], list(iou_thresholds), strict=True)
+    labels = engine.gt_labels(times, shard.counts_all[own], list(iou_thresholds), True, shard.device, ops)   # a11, on the device
     ranks, top_dist, top_idx = engine.corpus_ranks(shard, Q, own, labels, ops, k=return_topk, world=world)
     ranks = ranks.cpu().numpy()
 
     recalls = {}
     total = int(shard.mom_off_all[-1])
+    first = None
+    if "chance" in model_types:
+        # evaluate.py:68-72: ONE permutation per query (drawn in query order), shared by every IoU threshold; the chance
+        # rank is the first position of the permutation that holds a positive moment
+        lab_h = labels.cpu().numpy() if isinstance(labels, torch.Tensor) else labels
+        first = np.empty((len(iou_thresholds), len(own)), np.int64)
+        for q in range(len(own)):
+            perm = np.random.choice(np.arange(total), size=total, replace=False)
+            base = int(shard.mom_off_all[own[q]])
+            for r in range(len(iou_thresholds)):
+                pos = np.nonzero(lab_h[r, q])[0] + base
+                hit = np.nonzero(np.isin(perm, pos))[0]
+                if not len(hit):
+                    raise IndexError("index 0 is out of bounds for axis 0 with size 0 (no ground-truth-positive moment)")
+                first[r, q] = hit[0]
     for r, thr in enumerate(iou_thresholds):
         if "model" in model_types:
             recalls[("model", thr)] = {1: (ranks[r] < 1).astype(int), 10: (ranks[r] < 10).astype(int),
                                        100: (ranks[r] < 100).astype(int), "MR": ranks[r]}
         if "chance" in model_types:
-            first = np.empty(len(own), np.int64)
-            for q in range(len(own)):                      # same draw as evaluate.py:68, one per query
-                perm = np.random.choice(np.arange(total), size=total, replace=False)
-                base = int(shard.mom_off_all[own[q]])
-                pos = np.nonzero(labels[r, q])[0] + base
-                first[q] = np.nonzero(np.isin(perm, pos))[0][0]
-            recalls[("chance", thr)] = {1: (first < 1).astype(int), 10: (first < 10).astype(int),
-                                        100: (first < 100).astype(int), "MR": first}
+            recalls[("chance", thr)] = {1: (first[r] < 1).astype(int), 10: (first[r] < 10).astype(int),
+                                        100: (first[r] < 100).astype(int), "MR": first[r]}
     if preliminary and len(own) > preliminary and rank == 0:
-        for upto in range(preliminary + 1, len(own), preliminary):
+        for upto in range(preliminary + 1, len(own) + 1, preliminary):   # the reference prints at li = 100, 200, ... (li + 1 queries)
             print()
             for (mt, thr), rec in recalls.items():
                 part = get_metrics({k: v[:upto] for k, v in rec.items()})
@@ -145,7 +154,7 @@ def validate_epoch(model, video_iterator, lang_iterator, annotations, device, si
     video_index = {name: i for i, name in enumerate(names)}
     own = np.asarray([video_index[v] for v in q_videos], np.int64)
     times = [annotations[a]["times"] for a in annot_ids]
-    labels = engine.gt_label_table(times, shard.counts_all[own], thr_range, strict=False)
+    labels = engine.gt_labels(times, shard.counts_all[own], thr_range, False, shard.device, ops)   # main.py:161: >=
     kmax = max(atk) if size == -1 else 0
     ranks0, _, top_idx = engine.corpus_ranks(shard, Q, own, labels, ops, k=kmax, world=world)
     ranks = ranks0.cpu().numpy() + 1                                              # :169  "+ 1"
@@ -159,6 +168,7 @@ def validate_epoch(model, video_iterator, lang_iterator, annotations, device, si
            "pr_curve": {}}
     if size == -1:
         # positives among the top-k: only moments of the query's own video can be positive (:162-166)
+        labels = labels.cpu().numpy()
         top = top_idx.cpu().numpy()                                               # [Nq, kmax] global moment ids, -1 padded
         base = shard.mom_off_all[own][:, None]
         local = top - base

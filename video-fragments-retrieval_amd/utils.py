@@ -17,7 +17,7 @@ import numpy as np
 def generate_moments(num_segments: int):
     """All contiguous clip spans of a video with ``num_segments`` clips, in the reference's order:
     the ``n`` single clips first, then every pair ``(s, e)``, ``s < e`` lexicographically.  The position
-    in this list is the local moment id used by every kernel (``csrc/vfr_math.cuh: moment_index``)."""
+    in this list is the local moment id used by every kernel (``csrc/vfr_math.h: moment_index``)."""
     singles = [(t, t) for t in range(num_segments)]
     return singles + list(itertools.combinations(range(num_segments), 2))
 
