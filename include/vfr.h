@@ -123,6 +123,28 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
                        float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
                        const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, const int64_t *thr_seed,
                        void *workspace, size_t workspace_bytes, vfr_stream_t stream);
+/* The same pass with the clip distances taken from the GEMM form |v|^2 + |q|^2 - 2 v.q on the matrix cores
+ * (model/evaluate.py:53-58 as north_star's "MFMA batched query x clip GEMM"; csrc/score_mfma.h):
+ *   dtype VFR_MFMA_F32  fp32 MFMA pre-filter with a rigorous error margin; whatever the margin cannot decide is
+ *                       re-scored with the exact chain, so every output is BIT-IDENTICAL to vfr_score_topk_f32
+ *                       (shapes the pre-filter is not built for are simply handed to vfr_score_topk_f32);
+ *   dtype VFR_MFMA_BF16 bf16 operands, fp32 accumulate (BASELINE config 5): count_lt from the approximate
+ *                       distances, top-k = exact re-rank of the k + 28 best approximate candidates.  Needs D = 100,
+ *                       max_clips <= 21, num_rank in {0, 2}, k <= 253; VFR_EUNSUPPORTED otherwise.
+ * Arguments as vfr_score_topk_f32.                                                              */
+#define VFR_MFMA_F32 0
+#define VFR_MFMA_BF16 1
+size_t vfr_score_topk_mfma_workspace_bytes(int64_t Nq, int Nv, int total_clips, int k);
+int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets,
+                        const int64_t *moment_offsets, int Nv, int total_clips, int min_clips, int max_clips, int D,
+                        float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
+                        const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, const int64_t *thr_seed,
+                        int dtype, void *workspace, size_t workspace_bytes, vfr_stream_t stream);
+/* measurement hook (SYNCHRONISES the stream): what the last f32 call on `workspace` (same Nq, Nv, total_clips, k) left to
+ * the exact kernels.  stats_host[4] = {query groups of 64, groups handed to the exact fallback, (query, video) pairs
+ * re-scored exactly, capacity of the pair queues}.                                             */
+int vfr_score_topk_mfma_stats(const void *workspace, int64_t Nq, int Nv, int total_clips, int k, int64_t *stats_host,
+                              vfr_stream_t stream);
 /* merge G per-shard top-k lists (after the RCCL all-gather): part_dist/part_idx
  * [G, Nq, k] -> out [Nq, k], same (distance, id) order.                                        */
 int vfr_topk_merge_f32(const float *part_dist, const int64_t *part_idx, int G, int64_t Nq, int k, float *out_dist,

@@ -24,6 +24,16 @@ def vfr():
     return _vfr
 
 
+@pytest.fixture(params=["exact", "mfma"])
+def score_mode(request, vfr):
+    """Every scoring test runs twice: the exact VALU kernels, and the fp32 MFMA pre-filter + exact re-scoring path
+    (vfr_score_topk_mfma, dtype f32), whose outputs must be the same bits."""
+    old = vfr.DEFAULT_SCORE_MODE
+    vfr.DEFAULT_SCORE_MODE = request.param
+    yield request.param
+    vfr.DEFAULT_SCORE_MODE = old
+
+
 def dev(a, dtype=None):
     t = torch.from_numpy(np.ascontiguousarray(a))
     return (t.to(dtype) if dtype else t).to(DEV)
@@ -129,7 +139,7 @@ def _bank(vfr, V, off, id_base=0):
 
 
 @pytest.mark.parametrize("tag,clips", [("n6", 6), ("ragged", "didemo"), ("n21", 21)])
-def test_scoring_on_reference_embeddings(vfr, oracle, golden, tag, clips):
+def test_scoring_on_reference_embeddings(vfr, oracle, golden, tag, clips, score_mode):
     """a10-a12 on the reference's own embeddings: dense scores, own-video scores, fused top-k and rank counts."""
     g = golden(f"g2_scoring_{tag}.npz")
     Q, V, counts = g["query_emb"], g["visual_emb"], g["counts"]
@@ -162,7 +172,7 @@ def test_scoring_on_reference_embeddings(vfr, oracle, golden, tag, clips):
 
 @pytest.mark.parametrize("nq,nv,clips,k,D", [(1, 1, 6, 100, 100), (65, 3, 5, 7, 100), (130, 40, 21, 128, 100),
                                              (33, 17, "didemo", 100, 64), (5, 9, 64, 448, 100), (200, 600, 6, 100, 100)])
-def test_fused_topk_edge_shapes(vfr, oracle, nq, nv, clips, k, D):
+def test_fused_topk_edge_shapes(vfr, oracle, nq, nv, clips, k, D, score_mode):
     rs = np.random.RandomState(nq * 1000 + nv)
     counts = synth.clip_counts(nv, clips, seed=nq)
     off = synth.clip_offsets(counts)
@@ -173,7 +183,7 @@ def test_fused_topk_edge_shapes(vfr, oracle, nq, nv, clips, k, D):
     assert same(oi, wi) and same(od, wd)
 
 
-def test_fused_topk_exact_ties_break_by_moment_id(vfr, oracle):
+def test_fused_topk_exact_ties_break_by_moment_id(vfr, oracle, score_mode):
     """Duplicate videos -> many exactly equal scores; order must be (score, id)."""
     rs = np.random.RandomState(3)
     one = rs.randn(6, 100).astype(np.float32)
@@ -186,7 +196,7 @@ def test_fused_topk_exact_ties_break_by_moment_id(vfr, oracle):
     assert (np.diff(oi.cpu().numpy()[:, :50], axis=1) == 21).all()      # 50 copies of the best moment, ids 21 apart
 
 
-def test_topk_merge_and_shard_equivalence(vfr, oracle):
+def test_topk_merge_and_shard_equivalence(vfr, oracle, score_mode):
     """Per-shard top-k with id_base, merged, equals the unsharded top-k; counts add up (8e semantics)."""
     rs = np.random.RandomState(9)
     counts = synth.clip_counts(90, "didemo", seed=9)
@@ -209,7 +219,7 @@ def test_topk_merge_and_shard_equivalence(vfr, oracle):
     assert cnt[0].cpu().numpy().tolist() == oracle.rank_of(Q, V, off, rd, pick).tolist()
 
 
-def test_seeded_sharded_search_equals_unsharded(vfr, oracle):
+def test_seeded_sharded_search_equals_unsharded(vfr, oracle, score_mode):
     """The multi-GPU flow of engine.sharded_search replayed on one device: per-shard sample lists -> merged global
     sample -> its k-th key as thr_seed for the main passes -> merge(main parts + sample) == unsharded top-k."""
     from vfr_amd import engine
@@ -239,7 +249,7 @@ def test_seeded_sharded_search_equals_unsharded(vfr, oracle):
 
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tag,clips", [("n6", 6), ("ragged", "didemo"), ("n21", 21)])
-def test_evaluators_end_to_end_on_gpu(vfr, oracle, golden, tag, clips):
+def test_evaluators_end_to_end_on_gpu(vfr, oracle, golden, tag, clips, score_mode):
     """Drop-in surface on the device: same iterators, same dicts as the reference; embeddings == oracle bits."""
     from vfr_amd import evaluate as vevaluate
     from vfr_amd import evaluate_single as vsingle
@@ -328,7 +338,7 @@ def test_vgg_conv_launch_forms_bit_exact(vfr, oracle, cfg, T):
 
 
 # ---------------------------------------------------------------------------------------------
-def test_full_size_properties(vfr):
+def test_full_size_properties(vfr, score_mode):
     """BASELINE config 1 shape (10k videos x 21 clips) where the oracle is too slow: size-independent
     properties -- shard-and-merge == unsharded, top-k sorted with unique ids, rank count consistent with the
     list, sampled rows == dense kernel."""
@@ -511,7 +521,7 @@ def test_ranking_loss_forward_backward(vfr, oracle, golden, tag, nl):
 
 
 @pytest.mark.gpu
-def test_fused_scorer_randomised_differential(vfr):
+def test_fused_scorer_randomised_differential(vfr, score_mode):
     """A dozen random corpus shapes (uniform / ragged clip counts, tiny to mid-size, duplicated videos = exact ties, odd query
     counts, k from 1 to 300): the fused pass == dense kernel + stable sort, rank counts exact (tools/score_fuzz.py is the
     longer form of this)."""
@@ -666,7 +676,7 @@ def test_exchange_key_helpers_match_cpu_provider(vfr):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3, 8])
-def test_sharded_evaluate_through_kernels_equals_single(vfr, world):
+def test_sharded_evaluate_through_kernels_equals_single(vfr, world, score_mode):
     """engine's world > 1 flow (sample exchange -> seed -> main pass -> exchange -> merge; keys MIN, counts SUM; query
     slices gathered) on the real kernels: N ranks as N threads of this process with thread-barrier collectives
     (helpers.ThreadRanks).  Every rank's dict and top-k == the single-rank pass."""

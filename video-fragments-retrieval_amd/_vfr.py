@@ -42,6 +42,10 @@ SIGNATURES = {
     "vfr_score_topk_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "vfr_score_topk_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i64, _i32, _vp, _vp, _i32,
                                   _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vfr_score_topk_mfma_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "vfr_score_topk_mfma": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i64, _i32, _vp, _vp, _i32,
+                                   _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "vfr_score_topk_mfma_stats": (_i32, [_vp, _i64, _i32, _i32, _i32, ctypes.POINTER(ctypes.c_int64), _vp]),
     "vfr_topk_merge_f32": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "vfr_topk_pack_keys": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "vfr_topk_merge_keys": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
@@ -277,12 +281,23 @@ def score_own(Q: torch.Tensor, bank: VideoBank, own: torch.Tensor, eps: float = 
     return out
 
 
+# scoring mode of score_topk: "mfma" = fp32 MFMA pre-filter + exact re-scoring (bit-identical to "exact", the default),
+# "exact" = the exact VALU kernels only, "bf16" = bf16 MFMA operands, approximate (BASELINE config 5)
+SCORE_MODES = {"exact": None, "mfma": 0, "bf16": 1}
+DEFAULT_SCORE_MODE = os.environ.get("VFR_SCORE_MODE", "mfma")
+
+
 def score_topk(Q: torch.Tensor, bank: VideoBank, k: int, rank_dist=None, rank_idx=None, count_lt=None,
-               eps: float = 1e-6, workspace: torch.Tensor | None = None, thr_seed: torch.Tensor | None = None):
+               eps: float = 1e-6, workspace: torch.Tensor | None = None, thr_seed: torch.Tensor | None = None,
+               mode: str | None = None):
     """Fused scoring + top-k (+ rank counting for up to 4 keys per query).
 
     rank_dist / rank_idx: [R, Nq] (or [Nq]) -> count_lt [R, Nq] int64 is ADDED to (allocated zeroed when None).
+    ``mode``: see SCORE_MODES (None = DEFAULT_SCORE_MODE).
     Returns (dist [Nq,k] | None, idx [Nq,k] int64 | None, count_lt | None)."""
+    mode = mode or DEFAULT_SCORE_MODE
+    if mode not in SCORE_MODES:
+        raise RuntimeError(f"score_topk: unknown mode {mode!r}")
     Q = _dev(Q, torch.float32, "Q")
     Nq = Q.shape[0]
     od = torch.empty((Nq, k), dtype=torch.float32, device=Q.device) if k > 0 else None
@@ -297,20 +312,39 @@ def score_topk(Q: torch.Tensor, bank: VideoBank, k: int, rank_dist=None, rank_id
         count_lt = _dev(count_lt, torch.int64, "count_lt")
     if thr_seed is not None:
         thr_seed = _dev(thr_seed, torch.int64, "thr_seed")
-    nbytes = lib().vfr_score_topk_workspace_bytes(Nq, bank.num_videos, k)
+    dtype = SCORE_MODES[mode]
+    if dtype is None:
+        nbytes = lib().vfr_score_topk_workspace_bytes(Nq, bank.num_videos, k)
+    else:
+        nbytes = lib().vfr_score_topk_mfma_workspace_bytes(Nq, bank.num_videos, bank.total_clips, k)
     if workspace is None or workspace.numel() < nbytes:
         workspace = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=Q.device)
-    _check(lib().vfr_score_topk_f32(Q.data_ptr(), Nq, bank.emb.data_ptr(), bank.clip_off.data_ptr(),
-                                    bank.mom_off.data_ptr(), bank.num_videos, bank.total_clips, bank.min_clips,
-                                    bank.max_clips, bank.dim, eps, bank.id_base, k, _ptr(od), _ptr(oi), R, _ptr(rank_dist),
-                                    _ptr(rank_idx), _ptr(count_lt), _ptr(thr_seed), workspace.data_ptr(), nbytes, _stream()),
-           "vfr_score_topk_f32")
+    common = (Q.data_ptr(), Nq, bank.emb.data_ptr(), bank.clip_off.data_ptr(), bank.mom_off.data_ptr(), bank.num_videos,
+              bank.total_clips, bank.min_clips, bank.max_clips, bank.dim, eps, bank.id_base, k, _ptr(od), _ptr(oi), R,
+              _ptr(rank_dist), _ptr(rank_idx), _ptr(count_lt), _ptr(thr_seed))
+    if dtype is None:
+        _check(lib().vfr_score_topk_f32(*common, workspace.data_ptr(), nbytes, _stream()), "vfr_score_topk_f32")
+    else:
+        _check(lib().vfr_score_topk_mfma(*common, dtype, workspace.data_ptr(), nbytes, _stream()), "vfr_score_topk_mfma")
     return od, oi, count_lt
 
 
-def topk_workspace(Nq: int, num_videos: int, k: int, device) -> torch.Tensor:
-    return torch.empty((max(lib().vfr_score_topk_workspace_bytes(Nq, num_videos, k), 1),), dtype=torch.uint8,
-                       device=device)
+def score_mfma_stats(workspace: torch.Tensor, Nq: int, bank: VideoBank, k: int) -> dict:
+    """What the last ``mode="mfma"`` call on ``workspace`` left to the exact kernels (synchronises)."""
+    out = (ctypes.c_int64 * 4)()
+    _check(lib().vfr_score_topk_mfma_stats(workspace.data_ptr(), Nq, bank.num_videos, bank.total_clips, k, out, _stream()),
+           "vfr_score_topk_mfma_stats")
+    return {"groups": out[0], "fallback_groups": out[1], "exact_pairs": out[2], "queue_capacity": out[3],
+            "exact_pair_fraction": out[2] / float(max(1, Nq * bank.num_videos))}
+
+
+def topk_workspace(Nq: int, num_videos: int, k: int, device, total_clips: int | None = None) -> torch.Tensor:
+    """Workspace large enough for every scoring mode of a bank of ``num_videos`` videos / ``total_clips`` clips
+    (64 clips per video assumed when not given)."""
+    total_clips = int(total_clips) if total_clips is not None else 64 * num_videos
+    n = max(lib().vfr_score_topk_workspace_bytes(Nq, num_videos, k),
+            lib().vfr_score_topk_mfma_workspace_bytes(Nq, num_videos, total_clips, k), 1)
+    return torch.empty((n,), dtype=torch.uint8, device=device)
 
 
 def topk_merge(part_dist: torch.Tensor, part_idx: torch.Tensor):

@@ -16,6 +16,9 @@
 //     three-way threshold tests with a rigorous error margin, exact re-scoring of whatever the margin cannot decide.
 //   * keys are (fp32 bits of score << 32 | moment id): scores are >= 0 so unsigned order == the (score, id) lexicographic
 //     order, one 64-bit compare per test.
+#include <cstdlib>
+#include <vector>
+
 #include "vfr_common.h"
 #include "vfr_math.h"
 
@@ -24,6 +27,7 @@ namespace vfr {
 constexpr int NMAX_FUSED = 64;    // max clips per video on the fused path
 constexpr int NMAX_DENSE = 128;   // max clips per video on the dense / own paths
 constexpr unsigned long long KEY_MAX = ~0ull;
+constexpr unsigned long long KEY_EMPTY = 0x7F800000FFFFFFFFull;   // (+inf, max id): an unused slot of an exchanged list
 constexpr int MAX_RANK = 4;       // rank keys per query counted in one pass (IoU thresholds)
 
 // ------------------------------------------------------------------------------------------------
@@ -156,6 +160,8 @@ __device__ __attribute__((noinline)) int compact_buffer(unsigned long long *base
     return keep;
 }
 
+struct MfmaArgs;
+
 // read-only inputs are separate `const __restrict__` kernel parameters (not members of this struct):
 // only then does the backend know they are never written by the kernel and may use the (non-coherent)
 // scalar cache for the wave-uniform V / offset loads.
@@ -179,6 +185,9 @@ struct ScoreArgs {
     int prof_site;                                    // profiler site of this launch (0: chosen from the mode)
     int keep_all;                                     // 1: hand every appended key to the merge (no final per-column cut)
     int level_cap;                                    // > 0: only moments of at most this many clips are appended (stage A)
+    const int *group_mask;                            // != null: only query groups g with group_mask[g] != 0 are answered (MFMA fallback)
+    const struct MfmaArgs *mf_host;                   // HOST pointer, != null: launch the MFMA pre-filter kernel (score_mfma.h)
+    int mf_bf16;
 #ifdef VFR_SCORE_STAMPS
     unsigned long long *stamps;                       // debug build: per-phase s_memtime totals of the fused kernel
 #endif
@@ -199,6 +208,7 @@ __global__ __launch_bounds__(256) void score_kernel(const float *__restrict__ Qp
     const int task = blockIdx.x * 4 + wave;
     if (task >= a.num_groups * a.num_chunks) return;
     const int chunk = task / a.num_groups, group = task - chunk * a.num_groups;
+    if (a.group_mask && !a.group_mask[group]) return;
     float *ds = smem + (size_t)wave * a.ds_rows * 64;
 
     const int64_t qi = (int64_t)group * 64 + lane;
@@ -429,6 +439,7 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
     const int lane = threadIdx.x;
     const int task = blockIdx.x;
     const int chunk = task / a.num_groups, group = task - chunk * a.num_groups;
+    if (a.group_mask && !a.group_mask[group]) return;
     float *stage = smem;                              // [2][NC*100]  staged clip rows (double buffer)
     float *ds = smem + 2 * NC * FAST_D;               // [ceil(NT/NC)*NC][64] clip distances of the current video
     unsigned *lox_lds = reinterpret_cast<unsigned *>(ds + ((NT + NC - 1) / NC) * NC * 64);   // [NR][NT][64] when LOX_LDS
@@ -726,6 +737,8 @@ void score_fast_kernel(const float *__restrict__ Qp, const float *__restrict__ V
     }
 }
 
+#include "score_mfma.h"
+
 template <int NT, bool EXACT>
 static void launch_fast_nt(const ScoreArgs &a, int kpl, dim3 grid, size_t lds, hipStream_t st)
 {
@@ -760,13 +773,15 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
                                                                unsigned long long *__restrict__ out_keys,
                                                                unsigned long long *__restrict__ thr_seed,
                                                                float *__restrict__ out_dist,
-                                                               int64_t *__restrict__ out_idx, int seed_inclusive)
+                                                               int64_t *__restrict__ out_idx, int seed_inclusive,
+                                                               const int *__restrict__ group_mask)
 {
     constexpr int CAP = KPL * 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * 4 + wv;
     if (q >= Nq) return;
     const int group = (int)(q >> 6), ql = (int)(q & 63);
+    if (group_mask && !group_mask[group]) return;
     __shared__ int pre_s[4][MERGE_MAX_CHUNKS + 1];
     __shared__ unsigned long long pool_s[4][CAP];
     int *pre = pre_s[wv];
@@ -854,7 +869,6 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
 // the packed int64 keys the ranks exchange (KEY_EMPTY = (+inf, 0xffffffff) marks an unused slot).  Same LDS pool as the
 // task merge: all G*k keys are read as one flat sequence, CAP per round with the loads in flight together, and a key is
 // appended only if it beats the running k-th key -- after the first round almost nothing is, so a query costs ~2 sorts.
-constexpr unsigned long long KEY_EMPTY = 0x7F800000FFFFFFFFull;
 template <int KPL, bool PACKED>
 __global__ __launch_bounds__(256) void topk_merge_parts_kernel(const float *__restrict__ pd,
                                                                const int64_t *__restrict__ pi, int G, int64_t Nq,
@@ -1117,10 +1131,48 @@ static bool fast_applicable(const ScoreArgs &a)
            (a.ds_rows <= 6 || a.ds_rows == 21) && a.k + M <= 512;
 }
 
+
+// MFMA pre-filter launch (score_mfma.h): NT = 6 for banks of <= 6 clips per video, else 21 (any mix of lengths <= 21)
+static int launch_mfma(const ScoreArgs &a, hipStream_t st, int *cap_transposed)
+{
+    const MfmaArgs &m = *a.mf_host;
+    const int tasks = a.num_groups * a.num_chunks;
+    const int NT = a.ds_rows <= 6 ? 6 : 21, M = NT * (NT + 1) / 2;
+    const int kpl = (a.k > 0 && a.k + M > 256) ? 8 : 4;
+    if (cap_transposed) *cap_transposed = a.k > 0 ? kpl * 64 : 0;
+    const int RR = NT > 6 ? 48 : 32;
+    const size_t lds = ((size_t)RR * 64 + (size_t)a.num_rank * NT * 64) * sizeof(float);
+    ProfScope prof(a.prof_site ? a.prof_site : a.k == 0 ? SITE_SCORE_RANK : SITE_SCORE_FUSED, st);
+    dim3 grid((unsigned)tasks);
+#define VFR_MF(NTV, KPL, NRV, TOPKV, BF)                                                                                  \
+    hipLaunchKernelGGL((score_mfma_kernel<NTV, KPL, NRV, TOPKV, BF>), grid, dim3(64), lds, st, a.Q, a.V, a.clip_off, a.mom_off, a, m)
+#define VFR_MF_NT(NTV, BF)                                                                                                \
+    do {                                                                                                                  \
+        if (a.k > 0) {                                                                                                    \
+            if (a.num_rank == 0) { if (kpl == 4 && NTV == 6) VFR_MF(NTV, (NTV == 6 ? 4 : 8), 0, true, BF); else VFR_MF(NTV, 8, 0, true, BF); } \
+            else                 { if (kpl == 4 && NTV == 6) VFR_MF(NTV, (NTV == 6 ? 4 : 8), 2, true, BF); else VFR_MF(NTV, 8, 2, true, BF); } \
+        } else VFR_MF(NTV, 4, 2, false, BF);                                                                              \
+    } while (0)
+    if (NT == 6) { if (a.mf_bf16) VFR_MF_NT(6, true); else VFR_MF_NT(6, false); }
+    else         { if (a.mf_bf16) VFR_MF_NT(21, true); else VFR_MF_NT(21, false); }
+#undef VFR_MF_NT
+#undef VFR_MF
+    VFR_CHECK_LAUNCH("score_mfma_kernel");
+    return VFR_OK;
+}
+
+static bool mfma_applicable(int D, int max_clips, int num_rank, int k, int Nv, int total_clips)
+{
+    const int NT = max_clips <= 6 ? 6 : 21, M = NT * (NT + 1) / 2;
+    return D == FAST_D && max_clips <= 21 && (num_rank == 0 || num_rank == 2) && (k > 0 || num_rank > 0) && Nv > 0 &&
+           total_clips > 0 && (k == 0 || k + MF_EXTRA + M <= 512);
+}
+
 template <int MODE>
 static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st, int *cap_transposed = nullptr)
 {
     if (cap_transposed) *cap_transposed = 0;
+    if (MODE == 1 && a.mf_host) return launch_mfma(a, st, cap_transposed);
     const int tasks = a.num_groups * a.num_chunks;
     ProfScope prof(a.prof_site ? a.prof_site : MODE == 0 ? SITE_SCORE_DENSE : (a.force_generic && a.k > 0) ? SITE_SCORE_PREPASS
                    : a.k == 0 ? SITE_SCORE_RANK : SITE_SCORE_FUSED, st);
@@ -1165,6 +1217,87 @@ static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st, int *cap_tr
     else            { if (kpl == 4) VFR_LAUNCH(0, 4);   else VFR_LAUNCH(0, 8); }
 #undef VFR_LAUNCH
     VFR_CHECK_LAUNCH("score_kernel");
+    return VFR_OK;
+}
+
+
+// The whole fused pass over one bank with whichever scoring kernel `a` selects (exact: score_fast_kernel / score_kernel;
+// a.mf_host: the MFMA pre-filter): threshold ladder, merges, final list.  w.thr holds the initial per-query thresholds
+// (+inf keys, or the caller's seed: `seeded`).  out_keys != null: the final list is also written as sorted keys [Nq, k]
+// (KEY_MAX padded).  a.group_mask limits every launch to the flagged query groups.
+static int run_pass(ScoreArgs a, const TopkWs &w, bool seeded, float *out_dist, int64_t *out_idx,
+                    unsigned long long *out_keys, hipStream_t st)
+{
+    const int64_t Nq = a.Nq;
+    const int Nv = a.Nv, k = a.k;
+    a.buf = w.buf; a.buf_cnt = w.cnt; a.thr_global = w.thr;
+    a.v_lo = 0; a.v_hi = Nv;
+    plan_tasks(Nq, Nv, &a.num_groups, &a.num_chunks);
+    const int kpl = kpl_for(k);
+    int cap_t = 0, cap_pre = 0;
+    const unsigned long long *extra = nullptr;
+    auto merge = [&](const unsigned long long *buf, const int *cnt, int chunks, int capt, const unsigned long long *ex,
+                     unsigned long long *okeys, unsigned long long *seed, float *od, int64_t *oi, int seed_incl = 0) {
+        dim3 grid((unsigned)cdiv(Nq, 4)), block(256);
+        if (kpl == 4)
+            hipLaunchKernelGGL((topk_merge_tasks_kernel<4>), grid, block, 0, st, buf, cnt, a.num_groups, chunks, Nq, k,
+                               capt, ex, okeys, seed, od, oi, seed_incl, a.group_mask);
+        else
+            hipLaunchKernelGGL((topk_merge_tasks_kernel<8>), grid, block, 0, st, buf, cnt, a.num_groups, chunks, Nq, k,
+                               capt, ex, okeys, seed, od, oi, seed_incl, a.group_mask);
+    };
+    if (Nv > 0) {
+        // threshold ladder (see PRE_VIDEOS).  Stage A needs no seed and runs for every bank size (a 32-video sample shard is
+        // just a stage A plus its main pass); a caller-provided seed (the multi-GPU sample) replaces it.  Stage B only pays off on a long rest.
+        const bool fast = k > 0 && (a.mf_host != nullptr || fast_applicable(a));
+        const int na = (fast && !seeded) ? (Nv < PRE_VIDEOS ? Nv : PRE_VIDEOS) : 0;
+        // (after stage A's 64 videos a sixteenth of any corpus >= 256 tightens a lot; after a seed -- normally the k-th key of
+        // a 256-video global sample -- only a stage B of >= 512 videos can tighten further)
+        const int nb = (fast && Nv >= (seeded ? 4096 : 256)) ? pre_b_videos(Nv) : 0;
+        if (k > 0 && !fast && !seeded && Nv <= 512) {
+            // generic shapes, small banks: ~10 videos per task for the cooperative-compaction kernel
+            const int c = Nv / 10 < 1 ? 1 : Nv / 10;
+            a.num_chunks = c < a.num_chunks ? c : a.num_chunks;
+        }
+        if (na > 0) {
+            // Stage A only has to produce a VALID threshold cheaply: one video per wave-task, threshold +inf, and only the
+            // moments of <= PRE_LEVELS clips are kept (the best moments are short ones, and any k keys bound the k-th
+            // best from above); the merge's k-th key (+1: inclusive) becomes every query's threshold.  The sample videos
+            // are then scored like all others by the next stage, so nothing here needs rank keys or an output list.
+            ScoreArgs pre = a;
+            pre.v_lo = 0; pre.v_hi = na; pre.num_chunks = na; pre.num_rank = 0; pre.rank_dist = nullptr; pre.rank_idx = nullptr;
+            pre.buf = w.buf_pre; pre.buf_cnt = w.cnt_pre; pre.keep_all = 1; pre.level_cap = PRE_LEVELS;
+            pre.prof_site = a.prof_site ? a.prof_site : SITE_SCORE_PREPASS;
+            if (int rc = launch_score<1>(pre, kpl, st, &cap_pre)) return rc;
+            {
+                ProfScope prof(SITE_TOPK_MERGE, st);
+                merge(w.buf_pre, w.cnt_pre, na, cap_pre, nullptr, nullptr, w.thr, nullptr, nullptr, 1);
+            }
+            VFR_CHECK_LAUNCH("topk_merge_tasks_kernel(A)");
+        }
+        if (nb > 0) {
+            ScoreArgs b = a;                       // same buffers as the main launch: the stream orders B, its merge, C
+            b.v_hi = a.v_lo + nb;
+            b.prof_site = a.prof_site ? a.prof_site : SITE_SCORE_PREPASS;
+            if (int rc = launch_score<1>(b, kpl, st, &cap_t)) return rc;
+            {
+                ProfScope prof(SITE_TOPK_MERGE, st);
+                merge(w.buf, w.cnt, b.num_chunks, cap_t, extra, w.pre_keys2, w.thr, nullptr, nullptr);
+            }
+            VFR_CHECK_LAUNCH("topk_merge_tasks_kernel(B)");
+            extra = w.pre_keys2;
+            a.v_lo = b.v_hi;
+        }
+        if (int rc = launch_score<1>(a, kpl, st, &cap_t)) return rc;
+    } else if (k > 0) {
+        if (hipMemsetAsync(w.cnt, 0, (size_t)a.num_groups * a.num_chunks * 64 * 4, st) != hipSuccess)
+            return fail(VFR_EHIP, "score pass: hipMemsetAsync failed");
+    }
+    if (k > 0) {
+        ProfScope prof(SITE_TOPK_MERGE, st);
+        merge(w.buf, w.cnt, a.num_chunks, cap_t, extra, out_keys, nullptr, out_dist, out_idx);
+        VFR_CHECK_LAUNCH("topk_merge_tasks_kernel");
+    }
     return VFR_OK;
 }
 
@@ -1237,80 +1370,212 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
     vfr::ScoreArgs a{};
     a.Q = Q; a.Nq = Nq; a.V = V; a.clip_off = clip_offsets; a.mom_off = moment_offsets; a.Nv = Nv; a.D = D; a.eps = eps;
     a.id_base = id_base; a.k = k; a.num_rank = num_rank; a.rank_dist = rank_dist; a.rank_idx = rank_idx; a.count_lt = count_lt;
-    a.buf = w.buf; a.buf_cnt = w.cnt; a.thr_global = w.thr; a.ds_rows = max_clips < 1 ? 1 : max_clips;
+    a.ds_rows = max_clips < 1 ? 1 : max_clips;
     a.total_clips = total_clips;
     a.min_clips = min_clips;
-    a.v_lo = 0; a.v_hi = Nv;
-    vfr::plan_tasks(Nq, Nv, &a.num_groups, &a.num_chunks);
-    const int kpl = vfr::kpl_for(k);
-    int cap_t = 0, cap_pre = 0;
-    const unsigned long long *extra = nullptr;
-    auto merge = [&](const unsigned long long *buf, const int *cnt, int chunks, int capt, const unsigned long long *ex,
-                     unsigned long long *okeys, unsigned long long *seed, float *od, int64_t *oi, int seed_incl = 0) {
-        dim3 grid((unsigned)vfr::cdiv(Nq, 4)), block(256);
-        if (kpl == 4)
-            hipLaunchKernelGGL((vfr::topk_merge_tasks_kernel<4>), grid, block, 0, st, buf, cnt, a.num_groups, chunks, Nq, k,
-                               capt, ex, okeys, seed, od, oi, seed_incl);
-        else
-            hipLaunchKernelGGL((vfr::topk_merge_tasks_kernel<8>), grid, block, 0, st, buf, cnt, a.num_groups, chunks, Nq, k,
-                               capt, ex, okeys, seed, od, oi, seed_incl);
-    };
-    if (Nv > 0) {
-        if (k > 0) {
-            const hipError_t e = thr_seed ? hipMemcpyAsync(w.thr, thr_seed, (size_t)Nq * 8, hipMemcpyDeviceToDevice, st)
-                                          : hipMemsetAsync(w.thr, 0xFF, (size_t)Nq * 8, st);
-            if (e != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: threshold initialisation failed");
-        }
-        // threshold ladder (see PRE_VIDEOS).  Stage A needs no seed and runs for every bank size (a 32-video sample shard is
-        // just a stage A plus its main pass); a caller-provided seed (the multi-GPU sample) replaces it.  Stage B only pays off on a long rest.
-        const bool fast = k > 0 && vfr::fast_applicable(a);
-        const int na = (fast && !thr_seed) ? (Nv < vfr::PRE_VIDEOS ? Nv : vfr::PRE_VIDEOS) : 0;
-        // (after stage A's 64 videos a sixteenth of any corpus >= 256 tightens a lot; after a seed -- normally the k-th key of
-        // a 256-video global sample -- only a stage B of >= 512 videos can tighten further)
-        const int nb = (fast && Nv >= (thr_seed ? 4096 : 256)) ? vfr::pre_b_videos(Nv) : 0;
-        if (k > 0 && !fast && !thr_seed && Nv <= 512) {
-            // generic shapes, small banks: ~10 videos per task for the cooperative-compaction kernel
-            const int c = Nv / 10 < 1 ? 1 : Nv / 10;
-            a.num_chunks = c < a.num_chunks ? c : a.num_chunks;
-        }
-        if (na > 0) {
-            // Stage A only has to produce a VALID threshold cheaply: one video per wave-task, threshold +inf, and only the
-            // moments of <= PRE_LEVELS clips are kept (the best moments are short ones, and any k keys bound the k-th
-            // best from above); the merge's k-th key (+1: inclusive) becomes every query's threshold.  The sample videos
-            // are then scored like all others by the next stage, so nothing here needs rank keys or an output list.
-            vfr::ScoreArgs pre = a;
-            pre.v_lo = 0; pre.v_hi = na; pre.num_chunks = na; pre.num_rank = 0; pre.rank_dist = nullptr; pre.rank_idx = nullptr;
-            pre.buf = w.buf_pre; pre.buf_cnt = w.cnt_pre; pre.keep_all = 1; pre.level_cap = vfr::PRE_LEVELS;
-            pre.prof_site = vfr::SITE_SCORE_PREPASS;
-            if (int rc = vfr::launch_score<1>(pre, kpl, st, &cap_pre)) return rc;
-            {
-                vfr::ProfScope prof(vfr::SITE_TOPK_MERGE, st);
-                merge(w.buf_pre, w.cnt_pre, na, cap_pre, nullptr, nullptr, w.thr, nullptr, nullptr, 1);
-            }
-            VFR_CHECK_LAUNCH("topk_merge_tasks_kernel(A)");
-        }
-        if (nb > 0) {
-            vfr::ScoreArgs b = a;                       // same buffers as the main launch: the stream orders B, its merge, C
-            b.v_hi = a.v_lo + nb;
-            b.prof_site = vfr::SITE_SCORE_PREPASS;
-            if (int rc = vfr::launch_score<1>(b, kpl, st, &cap_t)) return rc;
-            {
-                vfr::ProfScope prof(vfr::SITE_TOPK_MERGE, st);
-                merge(w.buf, w.cnt, b.num_chunks, cap_t, extra, w.pre_keys2, w.thr, nullptr, nullptr);
-            }
-            VFR_CHECK_LAUNCH("topk_merge_tasks_kernel(B)");
-            extra = w.pre_keys2;
-            a.v_lo = b.v_hi;
-        }
-        if (int rc = vfr::launch_score<1>(a, kpl, st, &cap_t)) return rc;
-    } else if (k > 0) {
-        if (hipMemsetAsync(w.cnt, 0, (size_t)a.num_groups * a.num_chunks * 64 * 4, st) != hipSuccess)
-            return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: hipMemsetAsync failed");
+    if (Nv > 0 && k > 0) {
+        const hipError_t e = thr_seed ? hipMemcpyAsync(w.thr, thr_seed, (size_t)Nq * 8, hipMemcpyDeviceToDevice, st)
+                                      : hipMemsetAsync(w.thr, 0xFF, (size_t)Nq * 8, st);
+        if (e != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: threshold initialisation failed");
     }
+    return vfr::run_pass(a, w, thr_seed != nullptr, out_dist, out_idx, nullptr, st);
+}
+
+
+}  // extern "C"
+
+// ---- MFMA pre-filter path (score_mfma.h) ------------------------------------------------------------------------------
+namespace vfr {
+struct MfmaWs {
+    float *rv; int *fallback; int *queue_cnt; unsigned long long *cnt_ws; size_t zero_bytes; char *zero_base;
+    float *va; float4 *qmeta; unsigned *tab; unsigned short *vb; unsigned long long *queue; int queue_cap; int tasks, groups;
+    void *topk; size_t topk_bytes; size_t total;
+};
+static MfmaWs carve_mfma(void *base, int64_t Nq, int Nv, int total_clips, int k)
+{
+    MfmaWs w{};
+    int g, c;
+    plan_tasks(Nq, Nv, &g, &c);
+    w.groups = g; w.tasks = g * c;
+    const int nb = Nv >= 256 ? pre_b_videos(Nv) : 0;
+    const int per = (int)cdiv(Nv - nb > 0 ? Nv - nb : 1, c) + (int)cdiv(nb, c) + 2;
+    w.queue_cap = 16 * per < 128 ? 128 : 16 * per;                       // a quarter of the task's (query, video) pairs
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *p = static_cast<char *>(base) + off; off += align_up(bytes, 256); return p; };
+    w.zero_base = take(0);
+    w.rv = reinterpret_cast<float *>(take(4));
+    w.fallback = reinterpret_cast<int *>(take((size_t)g * 4));
+    w.queue_cnt = reinterpret_cast<int *>(take((size_t)w.tasks * 4));
+    w.cnt_ws = reinterpret_cast<unsigned long long *>(take((size_t)MAX_RANK * Nq * 8));
+    w.zero_bytes = off;
+    w.va = reinterpret_cast<float *>(take((size_t)total_clips * 4));
+    w.qmeta = reinterpret_cast<float4 *>(take((size_t)Nq * 16));
+    w.tab = reinterpret_cast<unsigned *>(take((size_t)Nq * 2 * 21 * MF_TAB * 4));
+    w.vb = reinterpret_cast<unsigned short *>(take((size_t)total_clips * 128 * 2));
+    w.queue = reinterpret_cast<unsigned long long *>(take((size_t)w.tasks * w.queue_cap * 8));
+    w.topk_bytes = carve_topk(nullptr, Nq, Nv, k > 0 ? k + MF_EXTRA : 0).total;
+    w.topk = take(w.topk_bytes);
+    w.total = off;
+    return w;
+}
+// threshold of a seeded pass in approximate-key space: seed score + 3 delta (delta for a clip floor of half the seed,
+// which the finisher verifies), id = max
+__global__ __launch_bounds__(256) void mfma_seed_kernel(const int64_t *__restrict__ seed, const float4 *__restrict__ qmeta,
+                                                        int64_t Nq, unsigned long long *__restrict__ thr)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= Nq) return;
+    const unsigned long long s = (unsigned long long)seed[q];
+    const float x = __uint_as_float((unsigned)(s >> 32));
+    unsigned long long t = KEY_MAX;
+    if (s < KEY_EMPTY && x < __builtin_inff() && x > 0.0f) {
+        const float delta = qmeta[q].z / (0.5f * x) + 190.0f * MF_U * x * 1.02f;
+        const float y = next_up((x + 3.0f * delta * 1.0001f) * 1.000001f);
+        t = y < __builtin_inff() ? (((unsigned long long)__float_as_uint(y) << 32) | 0xFFFFFFFFull) : KEY_MAX;
+    }
+    thr[q] = t;
+}
+}  // namespace vfr
+
+extern "C" {
+
+size_t vfr_score_topk_mfma_workspace_bytes(int64_t Nq, int Nv, int total_clips, int k)
+{
+    if (Nq < 0 || Nv < 0 || k < 0 || total_clips < 0) return 0;
+    const size_t a = vfr::carve_mfma(nullptr, Nq, Nv, total_clips, k).total, b = vfr_score_topk_workspace_bytes(Nq, Nv, k);
+    return a > b ? a : b;
+}
+
+int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets,
+                        const int64_t *moment_offsets, int Nv, int total_clips, int min_clips, int max_clips, int D,
+                        float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
+                        const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, const int64_t *thr_seed,
+                        int dtype, void *workspace, size_t workspace_bytes, vfr_stream_t stream)
+{
+    VFR_REQUIRE(dtype == VFR_MFMA_F32 || dtype == VFR_MFMA_BF16, VFR_EINVAL, "vfr_score_topk_mfma: dtype %d (0 = f32, 1 = bf16)", dtype);
+    VFR_REQUIRE(workspace && workspace_bytes >= vfr_score_topk_mfma_workspace_bytes(Nq, Nv, total_clips, k), VFR_EWORKSPACE,
+                "vfr_score_topk_mfma: workspace %zu < %zu bytes", workspace_bytes,
+                vfr_score_topk_mfma_workspace_bytes(Nq, Nv, total_clips, k));
+    if (!(Q && V && clip_offsets && moment_offsets && Nq > 0 && k >= 0 && num_rank >= 0) ||
+        !vfr::mfma_applicable(D, max_clips, num_rank, k, Nv, total_clips) || !vfr::opt_score_fast()) {
+        // shapes the pre-filter is not built for: the exact kernels give the same results in f32 mode
+        VFR_REQUIRE(dtype == VFR_MFMA_F32, VFR_EUNSUPPORTED,
+                    "vfr_score_topk_mfma(bf16): needs D = 100, <= 21 clips per video, 0 or 2 rank keys, k <= %d", 512 - 231 - vfr::MF_EXTRA);
+        return vfr_score_topk_f32(Q, Nq, V, clip_offsets, moment_offsets, Nv, total_clips, min_clips, max_clips, D, eps, id_base, k,
+                                  out_dist, out_idx, num_rank, rank_dist, rank_idx, count_lt, thr_seed, workspace, workspace_bytes, stream);
+    }
+    VFR_REQUIRE(k == 0 || (out_dist && out_idx), VFR_EINVAL, "vfr_score_topk_mfma: k > 0 needs out_dist/out_idx");
+    VFR_REQUIRE(num_rank == 0 || (rank_dist && rank_idx && count_lt), VFR_EINVAL,
+                "vfr_score_topk_mfma: num_rank > 0 needs rank_dist, rank_idx and count_lt");
+    VFR_REQUIRE(id_base >= 0, VFR_EINVAL, "vfr_score_topk_mfma: bad id_base");
+    hipStream_t st = vfr::as_stream(stream);
+    const bool bf16 = dtype == VFR_MFMA_BF16;
+    const int NT = max_clips <= 6 ? 6 : 21;
+    const int kp = k > 0 ? k + vfr::MF_EXTRA : 0;
+    vfr::MfmaWs mw = vfr::carve_mfma(workspace, Nq, Nv, total_clips, k);
+    vfr::TopkWs w = vfr::carve_topk(mw.topk, Nq, Nv, kp);
+    if (hipMemsetAsync(mw.zero_base, 0, mw.zero_bytes, st) != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: hipMemsetAsync failed");
+    vfr::MfmaArgs m{};
+    m.va = mw.va; m.qmeta = mw.qmeta; m.tab = mw.tab; m.cnt_ws = mw.cnt_ws; m.queue = mw.queue; m.queue_cnt = mw.queue_cnt;
+    m.queue_cap = mw.queue_cap; m.fallback = mw.fallback; m.vb = bf16 ? mw.vb : nullptr; m.rv = mw.rv;
+    {
+        vfr::ProfScope prof(vfr::SITE_SCORE_PREP, st);
+        hipLaunchKernelGGL(vfr::mfma_prep_v_kernel, dim3((unsigned)vfr::cdiv(total_clips, 4)), dim3(256), 0, st, V, total_clips, D, eps,
+                           mw.va, mw.rv, bf16 ? mw.vb : nullptr);
+        if (NT == 6)
+            hipLaunchKernelGGL((vfr::mfma_prep_q_kernel<6>), dim3((unsigned)vfr::cdiv(Nq, 64)), dim3(64), 0, st, Q, Nq, D, eps, mw.rv, num_rank,
+                               rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0);
+        else
+            hipLaunchKernelGGL((vfr::mfma_prep_q_kernel<21>), dim3((unsigned)vfr::cdiv(Nq, 64)), dim3(64), 0, st, Q, Nq, D, eps, mw.rv, num_rank,
+                               rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0);
+        if (k > 0) {
+            if (thr_seed)
+                hipLaunchKernelGGL(vfr::mfma_seed_kernel, dim3((unsigned)vfr::cdiv(Nq, 256)), dim3(256), 0, st, thr_seed, mw.qmeta, Nq, w.thr);
+            else if (hipMemsetAsync(w.thr, 0xFF, (size_t)Nq * 8, st) != hipSuccess)
+                return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: threshold initialisation failed");
+        }
+        VFR_CHECK_LAUNCH("mfma pre-pass");
+    }
+    vfr::ScoreArgs a{};
+    a.Q = Q; a.Nq = Nq; a.V = V; a.clip_off = clip_offsets; a.mom_off = moment_offsets; a.Nv = Nv; a.D = D; a.eps = eps;
+    a.id_base = id_base; a.k = kp; a.num_rank = num_rank; a.rank_dist = rank_dist; a.rank_idx = rank_idx; a.count_lt = count_lt;
+    a.ds_rows = max_clips < 1 ? 1 : max_clips;
+    a.total_clips = total_clips;
+    a.min_clips = min_clips;
+    a.mf_host = &m; a.mf_bf16 = bf16 ? 1 : 0;
+    if (int rc = vfr::run_pass(a, w, thr_seed != nullptr, nullptr, nullptr, kp > 0 ? w.pre_keys : nullptr, st)) return rc;
+    int g, c;
+    vfr::plan_tasks(Nq, Nv, &g, &c);
+    a.num_groups = g; a.num_chunks = c;
+    if (num_rank > 0 && !bf16) {
+        vfr::ProfScope prof(vfr::SITE_SCORE_PAIRS, st);
+        if (NT == 6)
+            hipLaunchKernelGGL((vfr::score_pairs_exact_kernel<6, 2>), dim3((unsigned)(g * c)), dim3(64), 0, st, Q, V, clip_offsets, moment_offsets,
+                               rank_dist, rank_idx, a, m);
+        else
+            hipLaunchKernelGGL((vfr::score_pairs_exact_kernel<21, 2>), dim3((unsigned)(g * c)), dim3(64), 0, st, Q, V, clip_offsets, moment_offsets,
+                               rank_dist, rank_idx, a, m);
+        VFR_CHECK_LAUNCH("score_pairs_exact_kernel");
+    }
+    {
+        vfr::ProfScope prof(vfr::SITE_SCORE_FINISH, st);
+        if (k > 0) {
+            const int uniform = (min_clips == max_clips && min_clips > 0) ? max_clips : 0;
+            dim3 grid((unsigned)vfr::cdiv(Nq, 4)), block(256);
+            if (kp <= 256)
+                hipLaunchKernelGGL((vfr::topk_finish_kernel<4>), grid, block, 0, st, w.pre_keys, kp, k, Q, Nq, V, clip_offsets, moment_offsets, Nv,
+                                   uniform, D, eps, id_base, mw.qmeta, mw.fallback, thr_seed, out_dist, out_idx, bf16 ? 0 : 1);
+            else
+                hipLaunchKernelGGL((vfr::topk_finish_kernel<8>), grid, block, 0, st, w.pre_keys, kp, k, Q, Nq, V, clip_offsets, moment_offsets, Nv,
+                                   uniform, D, eps, id_base, mw.qmeta, mw.fallback, thr_seed, out_dist, out_idx, bf16 ? 0 : 1);
+        }
+        if (num_rank > 0)
+            hipLaunchKernelGGL(vfr::mfma_commit_counts_kernel, dim3((unsigned)vfr::cdiv((int64_t)num_rank * Nq, 256)), dim3(256), 0, st, mw.cnt_ws,
+                               num_rank, Nq, bf16 ? nullptr : mw.fallback, count_lt);
+        VFR_CHECK_LAUNCH("mfma finisher");
+    }
+    if (bf16) return VFR_OK;
+    // ---- flagged query groups: the exact kernels, every launch limited to them (returns at once when nothing is flagged) ----
+    vfr::TopkWs wx = vfr::carve_topk(mw.topk, Nq, Nv, k);
+    vfr::ScoreArgs x{};
+    x.Q = Q; x.Nq = Nq; x.V = V; x.clip_off = clip_offsets; x.mom_off = moment_offsets; x.Nv = Nv; x.D = D; x.eps = eps;
+    x.id_base = id_base; x.k = k; x.num_rank = num_rank; x.rank_dist = rank_dist; x.rank_idx = rank_idx; x.count_lt = count_lt;
+    x.ds_rows = max_clips < 1 ? 1 : max_clips; x.total_clips = total_clips; x.min_clips = min_clips;
+    x.group_mask = mw.fallback;
+    x.prof_site = vfr::SITE_SCORE_FALLBACK;
     if (k > 0) {
-        vfr::ProfScope prof(vfr::SITE_TOPK_MERGE, st);
-        merge(w.buf, w.cnt, a.num_chunks, cap_t, extra, nullptr, nullptr, out_dist, out_idx);
-        VFR_CHECK_LAUNCH("topk_merge_tasks_kernel");
+        const hipError_t e = thr_seed ? hipMemcpyAsync(wx.thr, thr_seed, (size_t)Nq * 8, hipMemcpyDeviceToDevice, st)
+                                      : hipMemsetAsync(wx.thr, 0xFF, (size_t)Nq * 8, st);
+        if (e != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: threshold initialisation failed");
+    }
+    return vfr::run_pass(x, wx, thr_seed != nullptr, out_dist, out_idx, nullptr, st);
+}
+
+
+int vfr_score_topk_mfma_stats(const void *workspace, int64_t Nq, int Nv, int total_clips, int k, int64_t *stats_host,
+                              vfr_stream_t stream)
+{
+    VFR_REQUIRE(workspace && stats_host && Nq > 0 && Nv > 0, VFR_EINVAL, "vfr_score_topk_mfma_stats: bad argument");
+    hipStream_t st = vfr::as_stream(stream);
+    vfr::MfmaWs mw = vfr::carve_mfma(const_cast<void *>(workspace), Nq, Nv, total_clips, k);
+    std::vector<int> fb(mw.groups), qc(mw.tasks);
+    if (hipMemcpyAsync(fb.data(), mw.fallback, fb.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(qc.data(), mw.queue_cnt, qc.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma_stats: copy failed");
+    int64_t nf = 0, np = 0;
+    for (int v : fb) nf += v != 0;
+    for (int v : qc) np += v;
+    stats_host[0] = mw.groups; stats_host[1] = nf; stats_host[2] = np; stats_host[3] = (int64_t)mw.tasks * mw.queue_cap;
+    if (getenv("VFR_MFMA_DEBUG")) {
+        float rv = 0, qm[4]; unsigned tab[2 * 21 * 4];
+        (void)hipMemcpy(&rv, mw.rv, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(qm, mw.qmeta, 16, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(tab, mw.tab, sizeof tab, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mfma] R %.6g  q0: bq %.6g dfl %.6g E2 %.6g |q| %.6g\n", rv, qm[0], qm[1], qm[2], qm[3]);
+        for (int i = 0; i < 2 * 21; ++i)
+            fprintf(stderr, "[mfma] tab[%d] LOX %08x HIX %08x LOW %08x width %u  (lo sum %.7g)\n", i, tab[4 * i], tab[4 * i + 1], tab[4 * i + 2],
+                    tab[4 * i + 3], __builtin_bit_cast(float, tab[4 * i] - 1u));
     }
     return VFR_OK;
 }

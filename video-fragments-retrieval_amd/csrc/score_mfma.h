@@ -1,0 +1,763 @@
+// MFMA pre-filter for the fused scorer (included by score.hip, inside namespace vfr).
+//
+// The exact scorer spends two thirds of its time on the direct-difference distance ((v - q) + eps)^2: three VALU issues
+// per (query, clip, dimension), and not a GEMM.  Here the distances come from the GEMM form on the matrix cores,
+//
+//     d~^2(q, c) = a_c + b_q - 2 v_c.q,     a_c = |v_c|^2 + 2 eps sum(v_c) + D eps^2,     b_q = |q|^2 - 2 eps sum(q)
+//
+// (a_c, b_q accumulated in fp64 by a pre-pass, one MFMA fma per (query, clip, dimension)), and every decision the pass
+// makes with them carries a RIGOROUS error margin, so the emitted results stay those of the exact chain:
+//
+//   rank counts   per (rank key, span length L) the exact bounds LO/HI on the fp32 SUM of the L clip distances
+//                 (score < x <=> S <= LO, score <= x <=> S <= HI) are widened by Delta_L >= |S~ - S|: a moment is counted when
+//                 S~ <= LO - Delta_L, not counted when S~ > HI + Delta_L, and a (query, video) pair that holds a moment in
+//                 between -- or a clip closer than the distance floor the margin was derived for -- contributes nothing
+//                 here and is queued; score_pairs_exact_kernel re-scores the queued pairs with the canonical chain
+//                 (one pair per lane) and counts them exactly (ties by moment id).
+//   top-k         the selection machinery of score.hip runs unchanged on APPROXIMATE keys for k' = k + MF_EXTRA; the
+//                 finisher re-scores those k' candidates exactly and emits the k best.  The exact top-k is contained in
+//                 {s~ <= s~_(k) + 2 delta}, which is inside the k' list whenever s~_(k') > s~_(k) + 2 delta (or fewer than
+//                 k' candidates exist); the finisher checks that per query.
+//   fallback      a query group for which a check fails (more than MF_EXTRA candidates inside the margin -- duplicated
+//                 videos --, pair queue overflow, margins wider than the tables hold) is flagged on the device and answered
+//                 by the exact kernels of score.hip, launched with a group mask; everything else returns at once there.
+//
+// Error margin.  With R = max_c |v_c|, G = (R + |q|)^2 (+ the eps terms):
+//   * MFMA side: the K = 100 chain is cut into 6 blocks of 16 products and one of 4, each block summed by
+//     v_mfma_f32_16x16x4_f32 from zero (a k-ordered fp32 fma chain: error <= 16 u sum|2 q_k v_k| <= 8 u G over the blocks),
+//     the 7 block sums, a_c and b_q added by 8 fp32 adds of partial sums <= G, a_c and b_q each rounded once from fp64:
+//     |d~^2 - d*^2| <= E2 := 20 u G  (17 u G by the count above).  Hence |d~ - d*| <= E2 / d~ <= E2 / dfl whenever d~ >= dfl.
+//   * oracle side: t_k = fl(fl(v_k - q_k) + eps), S = fma chain of t_k^2: |S - S*| <= 105 u S*, so the exact-path distance d
+//     obeys |d - d*| <= 53.5 u d*;  v_sqrt_f32 on the approximate side adds 2 u d~.
+//   * sums of L distances add (L - 1) u S on either side.
+//   => |S~ - S| <= L E2 / dfl + (56 + 2 L) u S  =: Delta_L   for every moment of a pair whose clips all have d~ >= dfl.
+// dfl = 3/4 of the smaller rank-key distance of the query (per-query constant); for the top-k check the floor is the best
+// approximate score itself (no clip is closer to the query than the best single-clip moment).
+//
+// bf16 mode (BASELINE config 5): operands rounded to bf16, fp32 accumulate (v_mfma_f32_16x16x32_bf16), a_c / b_q from the
+// fp32 data.  Approximate by design: rank counts use the approximate distances as they are, the top-k is the exact re-rank
+// of the k' best bf16 candidates.  No margins, no queue, no fallback.
+#pragma once
+
+constexpr int MF_EXTRA = 28;                 // k' = k + MF_EXTRA candidates by approximate key
+constexpr float MF_U = 5.9604645e-8f;        // 2^-24
+constexpr int MF_TAB = 4;                    // table words per (query, key, L): LO, HI (exact, exclusive bit bounds), LO wide, width
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct MfmaArgs {
+    const float *va;                         // [total_clips] a_c
+    const float4 *qmeta;                     // [Nq] {b_q, dfl, E2, |q|}
+    const unsigned *tab;                     // [Nq][NR][NT][MF_TAB]
+    unsigned long long *cnt_ws;              // [NR][Nq] rank counts of this call (committed to count_lt at the end)
+    unsigned long long *queue;               // [tasks][queue_cap] ambiguous pairs: query << 32 | video << 2 | key mask
+    int *queue_cnt;                          // [tasks]
+    int queue_cap;
+    int *fallback;                           // [groups] != 0: answered by the exact kernels
+    const unsigned short *vb;                // bf16 mode: V as bf16 [total_clips][128] (zero padded)
+    const float *rv;                         // [1] max clip norm (pre-pass)
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pre-passes
+// ---------------------------------------------------------------------------------------------------------------------
+// one wave per clip row: a_c in fp64, max norm (float atomicMax on the bits: norms are >= 0), optional bf16 copy
+__global__ __launch_bounds__(256) void mfma_prep_v_kernel(const float *__restrict__ V, int total_clips, int D, float eps,
+                                                          float *__restrict__ va, float *__restrict__ rv,
+                                                          unsigned short *__restrict__ vb)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= total_clips) return;
+    const float *v = V + row * D;
+    double s2 = 0.0, s1 = 0.0;
+    for (int k = lane; k < D; k += 64) { const double x = v[k]; s2 += x * x; s1 += x; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { s2 += __shfl_xor(s2, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    if (lane == 0) {
+        va[row] = (float)(s2 + 2.0 * (double)eps * s1 + (double)D * (double)eps * (double)eps);
+        // (one contended atomic per row would serialise the launch: only rows that can raise the maximum issue one)
+        const unsigned nb = __float_as_uint((float)__builtin_sqrt(s2) * 1.0000002f);
+        if (nb > __hip_atomic_load(reinterpret_cast<unsigned *>(rv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(reinterpret_cast<unsigned *>(rv), nb);
+    }
+    if (vb)
+        for (int k = lane; k < 128; k += 64) {
+            const __bf16 b = (__bf16)(k < D ? v[k] : 0.0f);
+            vb[row * 128 + k] = __builtin_bit_cast(unsigned short, b);
+        }
+}
+
+// one thread per query: b_q, |q|, E2, the distance floor; then the threshold table rows of its rank keys
+template <int NT>
+__global__ __launch_bounds__(64) void mfma_prep_q_kernel(const float *__restrict__ Q, int64_t Nq, int D, float eps,
+                                                         const float *__restrict__ rv, int NR,
+                                                         const float *__restrict__ rank_dist, float4 *__restrict__ qmeta,
+                                                         unsigned *__restrict__ tab, int bf16_mode)
+{
+    const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (q >= Nq) return;
+    const float *p = Q + q * D;
+    double s2 = 0.0, s1 = 0.0;
+    for (int k = 0; k < D; ++k) { const double x = p[k]; s2 += x * x; s1 += x; }
+    const float bq = (float)(s2 - 2.0 * (double)eps * s1);
+    const float qn = (float)__builtin_sqrt(s2) * 1.0000002f;
+    const float R = *rv;
+    // G bounds every partial sum of the approximate chain: (R + |q|)^2 + 2 eps sqrt(D) (R + |q|) + D eps^2, rounded up
+    const float rs = (R + qn) * 1.000001f;
+    const float G = (rs * rs + 2.0f * eps * __builtin_sqrtf((float)D) * rs + (float)D * eps * eps) * 1.00001f;
+    const float E2 = 20.0f * MF_U * G;
+    float xmin = __builtin_inff();
+    for (int r = 0; r < NR; ++r) { const float x = rank_dist[r * Nq + q]; xmin = x < xmin ? x : xmin; }
+    const float dfl = NR > 0 && xmin < __builtin_inff() ? 0.75f * xmin : 0.0f;
+    qmeta[q] = make_float4(bq, dfl, E2, qn);
+    for (int r = 0; r < NR; ++r) {
+        const float x = rank_dist[r * Nq + q];
+        for (int L = 1; L <= NT; ++L) {
+            unsigned *t = tab + ((q * NR + r) * NT + (L - 1)) * MF_TAB;
+            const float lo = sum_bound<true>(x, L), hi = sum_bound<false>(x, L);
+            const unsigned LOX = min(excl_bound(lo), 0x7F800000u), HIX = min(excl_bound(hi), 0x7F800000u);
+            unsigned LOW = LOX, HIW = HIX;
+            if (!bf16_mode && x < __builtin_inff()) {
+                // Delta_L: see the header.  S is at most hi + Delta_L near the window; (56 + 2L) u S with 2 % head-room.
+                const float Sref = (hi > 0.0f ? hi : 0.0f) + (float)L * 1e-3f;
+                const float delta = dfl > 0.0f ? ((float)L * E2 / dfl + (float)(56 + 2 * L) * MF_U * Sref * 1.02f) * 1.0001f
+                                               : __builtin_inff();
+                float low = lo - delta;                                   // lo = -1: no sum is below the key
+                low = low > 0.0f ? next_down(low) : -1.0f;
+                float hiw = (hi > 0.0f ? hi : 0.0f) + delta;
+                hiw = hiw < __builtin_inff() ? next_up(hiw) : hiw;
+                LOW = min(excl_bound(low), 0x7F800000u);
+                HIW = min(excl_bound(hiw), 0x7F800000u);
+                if (HIW < HIX) HIW = HIX;
+                if (LOW > LOX) LOW = LOX;
+            }
+            t[0] = LOX; t[1] = HIX; t[2] = LOW; t[3] = HIW - LOW;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// approximate fused kernel.  thread = query for the moment triangle (as score_fast_kernel); the distances of 16-clip
+// column tiles x the wave's 64 queries come from 100 (f32) / 16 (bf16) MFMAs per tile, the accumulator tiles go through a
+// per-wave LDS ring (clip-major rows of 64 queries, 16-byte chunks XOR-swizzled by row so that both the b128 tile writes
+// and the per-query reads are bank-conflict free) and a video is processed as soon as its last clip has been written.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT, int KPL, int NR, bool TOPK, bool BF16>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
+void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ Vp, const int32_t *__restrict__ clip_off,
+                       const int64_t *__restrict__ mom_off, ScoreArgs a, MfmaArgs m)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CAP = KPL * 64, RR = NT > 6 ? 48 : 32, NRR = NR > 0 ? NR : 1, NW = (NT + 2) / 3;
+    constexpr int KS = BF16 ? 4 : 25;                                   // MFMA k-steps per tile
+    const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+    const int task = blockIdx.x;
+    const int chunk = task / a.num_groups, group = task - chunk * a.num_groups;
+    float *ring = smem;                                                  // [RR][64] approximate d^2 - b_q
+    unsigned *lox_lds = reinterpret_cast<unsigned *>(smem + RR * 64);    // [NR][NT][64] widened lower bounds
+
+    const int64_t qi = (int64_t)group * 64 + lane;
+    const bool active = qi < a.Nq;
+    const float4 meta = m.qmeta[active ? qi : a.Nq - 1];
+    const float bq = meta.x, dfl = (active && !BF16) ? meta.y : 0.0f;
+
+    // ---- A operand: -2 q, queries 16t + j of the group, k-slots of this lane's quarter g ----
+    float Af[BF16 ? 1 : 4][BF16 ? 1 : 25];
+    bf16x8 Ab[BF16 ? 4 : 1][BF16 ? 4 : 1];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int64_t row = (int64_t)group * 64 + 16 * t + j;
+        row = row < a.Nq ? row : a.Nq - 1;
+        const float *p = Qp + row * FAST_D;
+        if constexpr (!BF16) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float4 x = *reinterpret_cast<const float4 *>(p + 24 * g + 4 * i);
+                Af[t][4 * i] = -2.0f * x.x; Af[t][4 * i + 1] = -2.0f * x.y; Af[t][4 * i + 2] = -2.0f * x.z; Af[t][4 * i + 3] = -2.0f * x.w;
+            }
+            Af[t][24] = -2.0f * p[96 + g];
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = 32 * s + 8 * g + i;
+                    Ab[t][s][i] = (__bf16)(e < FAST_D ? -2.0f * p[e < FAST_D ? e : 0] : 0.0f);
+                }
+            }
+        }
+    }
+
+    const int v0 = a.v_lo + (int)((int64_t)(a.v_hi - a.v_lo) * chunk / a.num_chunks);
+    const int v1 = a.v_lo + (int)((int64_t)(a.v_hi - a.v_lo) * (chunk + 1) / a.num_chunks);
+
+    // ---- thresholds ----
+    unsigned long long thr = KEY_MAX;
+    int cnt = 0, nlt[NRR] = {0};
+    unsigned long long *col = TOPK ? a.buf + (size_t)task * 64 * CAP : nullptr;
+    float thrf = __builtin_inff();                                       // top-k filter: a moment of L clips may enter when sum <= thrf * L (* 1 + 8u)
+    unsigned wpk[NW];                                                    // 10-bit window width per span length (max over keys), 3 per register
+    bool wide = false;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) wpk[w] = 0u;
+#pragma unroll
+    for (int L = 1; L <= NT; ++L) {
+        unsigned wd = 0u;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const unsigned *t = m.tab + (((active ? qi : 0) * NR + r) * NT + (L - 1)) * MF_TAB;
+            const uint4 e = *reinterpret_cast<const uint4 *>(t);
+            lox_lds[(r * NT + (L - 1)) * 64 + lane] = active ? (BF16 ? e.x : e.z) : 0u;
+            const unsigned w_ = (active && !BF16) ? e.w : 0u;
+            wd = w_ > wd ? w_ : wd;
+        }
+        wide = wide || wd > 1023u;
+        wpk[(L - 1) / 3] |= (wd & 1023u) << (10 * ((L - 1) % 3));
+        asm volatile("" ::: "memory");               // one level's table words in flight at a time (not 42 x 4 registers)
+    }
+    if (!active) thrf = -1.0f;
+
+    // ---- pair queue of this task (appended to by every launch of the call) ----
+    int qn = NR > 0 && !BF16 ? m.queue_cnt[task] : 0;
+    unsigned long long *queue = m.queue + (size_t)task * m.queue_cap;
+
+    // ---- B operand: the clip rows of a tile, k-block by k-block ----
+    // f32: 6 blocks of 4 k-steps (one 16-byte load per lane: elements 24 g + 4 b .. + 3 of row j) + the 25th step (element
+    // 96 + g).  Only a window of three blocks is held in registers: block b + 3 is requested while block b feeds its 16 MFMAs,
+    // the last three requests of a tile are the first three blocks of the NEXT tile, which land under the moment triangles.
+    const int64_t last_row = (int64_t)a.total_clips - 1;
+    float4 Bq[BF16 ? 1 : 3];
+    float Bl = 0.0f, Bl_next = 0.0f;                                     // 25th k-step of this / the next tile
+    bf16x8 Bb[BF16 ? 4 : 1];
+    float acv_next = 0.0f;
+    auto brow = [&](int64_t c_tile) -> int64_t { const int64_t row = c_tile + j; return row < last_row ? row : last_row; };
+    auto bblock = [&](int64_t row, int b) -> float4 { return *reinterpret_cast<const float4 *>(Vp + row * FAST_D + 24 * g + 4 * b); };
+    auto bload_bf16 = [&](int64_t c_tile) {
+        const int64_t row = brow(c_tile);
+        acv_next = m.va[row];
+        const unsigned short *p = m.vb + row * 128;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Bb[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(p + 32 * s + 8 * g));
+    };
+
+    // per-lane ring addressing (bytes): write = row j of the tile, chunk (4t + g) ^ j; read = chunk (lane >> 2) ^ (row & 15)
+    const unsigned rd_lane = (unsigned)(((lane >> 2) << 4) | ((lane & 3) << 2));
+    auto ring_read = [&](int row) -> float {                             // row wave-uniform
+        const unsigned off = (rd_lane ^ ((unsigned)(row & 15) << 4)) + (unsigned)row * 256u;
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ring) + off);
+    };
+
+    if (v0 >= v1) {
+        if (TOPK) a.buf_cnt[(size_t)task * 64 + lane] = 0;
+        return;
+    }
+    const int c_lo = clip_off[v0], c_hi = clip_off[v1];
+    int v = v0, c_cur = c_lo, c_nxt = clip_off[v0 + 1];
+    int64_t m_cur = mom_off[v0];
+    if constexpr (BF16) bload_bf16(c_lo);
+    else {
+        const int64_t row = brow(c_lo);
+        acv_next = m.va[row];
+        Bl_next = Vp[row * FAST_D + 96 + g];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) Bq[b] = bblock(row, b);
+    }
+    int tile_row0 = 0;
+    for (int c_tile = c_lo; c_tile < c_hi || v < v1; c_tile += 16) {
+        // ---- 64 queries x 16 clips on the matrix cores ----
+        f32x4 acc[4];
+        const float acv_cur = acv_next;
+        if constexpr (!BF16) {
+            const int64_t row = brow(c_tile), row_n = brow((int64_t)c_tile + 16);
+            Bl = Bl_next;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const float4 cur = Bq[b % 3];
+                const float bs[4] = {cur.x, cur.y, cur.z, cur.w};
+                f32x4 part[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) part[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#ifdef VFR_MF_SKIP_MFMA
+                        part[t][s4] += Af[t][4 * b + s4] * bs[s4];      // timing experiment: one VALU op instead of the MFMA
+#else
+                        part[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Af[t][4 * b + s4], bs[s4], part[t], 0, 0, 0);
+#endif
+                }
+                Bq[b % 3] = b < 3 ? bblock(row, b + 3) : bblock(row_n, b - 3);
+                if (b == 3) { Bl_next = Vp[row_n * FAST_D + 96 + g]; acv_next = m.va[row_n]; }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = b == 0 ? part[t] : acc[t] + part[t];
+            }
+            {
+                f32x4 part[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) part[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Af[t][24], Bl, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = acc[t] + part[t];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ab[t][s], Bb[s], acc[t], 0, 0, 0);
+            }
+            bload_bf16((int64_t)c_tile + 16);                            // next tile's operands land under the triangles
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 o = acc[t] + acv_cur;
+            const unsigned off = (unsigned)(tile_row0 + j) * 256u + ((unsigned)((4 * t + g) ^ j) << 4);
+            *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(ring) + off) = o;
+        }
+        tile_row0 = tile_row0 + 16 == RR ? 0 : tile_row0 + 16;
+        const int c_done = c_tile + 16;
+
+        // ---- every video whose last clip is in the ring ----
+        while (v < v1 && c_nxt <= c_done) {
+            const int c0 = c_cur, n = c_nxt - c_cur;
+            const int64_t mbase = m_cur;
+            c_cur = c_nxt;
+            ++v;
+            if (v < v1) { c_nxt = clip_off[v + 1]; m_cur = mom_off[v]; }
+            int r0 = (c0 - c_lo) % RR;
+#ifdef VFR_MF_SKIP_TRI
+            if (ring_read(r0) == 123.456f) nlt[0] += (int)mbase + n;    // timing experiment: no triangle
+            continue;
+#endif
+            if (TOPK) {
+                if (__ballot(cnt > CAP - n * (n + 1) / 2)) {
+                    __threadfence_block();
+                    const unsigned long long before = thr;
+                    lane_tighten(col, lane, a.k, &cnt, &thr);
+                    __threadfence_block();
+                    if (thr < before && active) __hip_atomic_fetch_min(a.thr_global + qi, thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (((v - v0) & 7) == 1 && active) {
+                    const unsigned long long gthr = __hip_atomic_load(a.thr_global + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    thr = gthr < thr ? gthr : thr;
+                }
+                // score <= thr  =>  fl(sum / L) <= thr  =>  sum <= thr L (1 + u): the level test is one multiply, no table
+                if (active) thrf = thr == KEY_MAX ? __builtin_inff() : __uint_as_float((unsigned)(thr >> 32)) * 1.000001f;
+            }
+            // approximate distances of this lane's query to the n clips
+            float d[NT], sums[NT];
+            float dmin = __builtin_inff();
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                int row = r0 + c;
+                row = row >= RR ? row - RR : row;
+                const float x2 = ring_read(row) + bq;
+                const float dd = __builtin_amdgcn_sqrtf(x2 > 0.0f ? x2 : 0.0f);
+                d[c] = c < n ? dd : __builtin_inff();
+                dmin = d[c] < dmin ? d[c] : dmin;
+            }
+            int amb[NRR] = {0}, cv[NRR] = {0};
+            unsigned lvl = 0;
+#pragma unroll
+            for (int L = 1; L <= NT; ++L) {
+                static_assert(NT <= 32, "one 32-bit sign collector per level");
+                unsigned lx[NRR], umin[NRR], below[NRR];
+                const unsigned wd = (wpk[(L - 1) / 3] >> (10 * ((L - 1) % 3))) & 1023u;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    below[r] = 0u;
+                    lx[r] = lox_lds[(r * NT + (L - 1)) * 64 + lane];
+                    umin[r] = 0xFFFFFFFFu;
+                }
+                float tmin = __builtin_inff();
+#pragma unroll
+                for (int s = 0; s + L <= NT; ++s) {
+                    const float de = d[s + L - 1];
+                    const float sum = L == 1 ? de : sums[s] + de;
+                    sums[s] = sum;
+                    const unsigned sb = __float_as_uint(sum);
+                    if (TOPK) tmin = sum < tmin ? sum : tmin;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const unsigned u = sb - lx[r];
+                        below[r] = __builtin_amdgcn_alignbit(below[r], u, 31);
+                        umin[r] = u < umin[r] ? u : umin[r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    cv[r] += __builtin_popcount(below[r]);
+                    amb[r] += umin[r] < wd ? 1 : 0;
+                }
+                if (TOPK) lvl = lvl + lvl + (tmin <= thrf * (float)L ? 1u : 0u);
+                if (NR == 2) asm volatile("" : "+v"(cv[0]), "+v"(cv[NR > 1 ? 1 : 0]), "+v"(amb[0]), "+v"(amb[NR > 1 ? 1 : 0]), "+v"(lvl));
+                else asm volatile("" : "+v"(lvl));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (NR > 0) {
+                unsigned rmask = 0u;
+                const bool low = !BF16 && (wide || dmin < dfl);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const bool am = low || amb[r] != 0;
+                    nlt[r] += am ? 0 : cv[r];
+                    rmask |= (am ? 1u : 0u) << r;
+                }
+                if (!BF16) {
+                    const bool push = active && rmask != 0u;
+                    const unsigned long long mm = __ballot(push);
+                    if (mm) {
+                        const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
+                        if (push && pos < m.queue_cap)
+                            queue[pos] = ((unsigned long long)qi << 32) | ((unsigned long long)(unsigned)(v - 1) << 2) | rmask;
+                        qn += __builtin_popcountll(mm);
+                    }
+                }
+            }
+            if (TOPK && lvl != 0) {
+                // candidates by approximate key: the flagged levels again, then only the moments under the bound
+                auto dist_at = [&](int c) -> float {                     // per-lane clip index
+                    int row = r0 + c;
+                    row = row >= RR ? row - RR : row;
+                    const unsigned off = (rd_lane ^ ((unsigned)(row & 15) << 4)) + (unsigned)row * 256u;
+                    const float x2 = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ring) + off) + bq;
+                    return __builtin_amdgcn_sqrtf(x2 > 0.0f ? x2 : 0.0f);
+                };
+                // (the distances as opaque values: otherwise the level sums below are "the same" expressions as the triangle's
+                // and the compiler keeps all 231 of those alive up to here)
+                float dd[NT];
+#pragma unroll
+                for (int c = 0; c < NT; ++c) { dd[c] = d[c]; asm volatile("" : "+v"(dd[c])); }
+#pragma unroll
+                for (int L = 1; L <= NT; ++L) {
+                    if (((lvl >> (NT - L)) & 1u) && (a.level_cap == 0 || L <= a.level_cap)) {
+                        const float hx = thrf * (float)L;
+                        unsigned pm = 0;
+#pragma unroll
+                        for (int s = 0; s + L <= NT; ++s) {
+                            float sum = dd[s];
+#pragma unroll
+                            for (int e = s + 1; e < s + L; ++e) sum += dd[e];
+                            pm |= (sum <= hx ? 1u : 0u) << s;
+                        }
+                        while (pm) {
+                            const int s = __builtin_ctz(pm);
+                            pm &= pm - 1u;
+                            if (s + L <= n) {
+                                float sum = dist_at(s);
+#pragma nounroll
+                                for (int e = s + 1; e < s + L; ++e) sum += dist_at(e);
+                                const float sc = sum / (float)L;
+                                const unsigned id = (unsigned)(a.id_base + mbase + moment_index(n, s, s + L - 1));
+                                const unsigned long long key = make_key(sc, id);
+                                if (key < thr) { col[(size_t)cnt * 64 + lane] = key; ++cnt; }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (NR > 0) {
+        if (active)
+            for (int r = 0; r < NR; ++r)
+                if (nlt[r]) atomicAdd(m.cnt_ws + r * a.Nq + qi, (unsigned long long)nlt[r]);
+        if (!BF16 && lane == 0) {
+            m.queue_cnt[task] = qn;
+            if (qn > m.queue_cap) m.fallback[group] = 1;
+        }
+    }
+    if (TOPK) {
+        if (!a.keep_all) {
+            __threadfence_block();
+            lane_tighten(col, lane, a.k, &cnt, &thr);
+            __threadfence_block();
+        }
+        a.buf_cnt[(size_t)task * 64 + lane] = active ? cnt : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// exact re-scoring of the queued (query, video) pairs.  One wave per task queue, 64 pairs at a time:
+//   phase 1  the canonical distance chains, lane = (pair, clip): the queue is in video order, so the pairs of one video are
+//            consecutive; the video's clip rows are staged into LDS with coalesced 16-byte loads (the next video's rows in
+//            flight meanwhile) and every lane runs one k-ascending chain -- v from LDS, q from the pair's query row (L1);
+//   phase 2  lane = pair: its clip distances come back through LDS, then the moment triangle against the EXACT bounds of
+//            the table (ties broken by moment id on the exact score).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT, int NR>
+__global__ __launch_bounds__(64) void score_pairs_exact_kernel(const float *__restrict__ Qp, const float *__restrict__ Vp,
+                                                               const int32_t *__restrict__ clip_off,
+                                                               const int64_t *__restrict__ mom_off,
+                                                               const float *__restrict__ rank_dist,
+                                                               const int64_t *__restrict__ rank_idx, ScoreArgs a, MfmaArgs m)
+{
+    constexpr int ROW4 = FAST_D / 4, NLD = (NT * ROW4 + 63) / 64, QR = 16, NLQ = (QR * ROW4 + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float vst[NT * FAST_D];     // clip rows of the current video
+    __shared__ __attribute__((aligned(16))) float qst[QR * FAST_D];     // query rows of the current run of pairs (<= QR)
+    __shared__ float dx[64 * NT];                                        // exact distances [pair][clip]
+    const int lane = threadIdx.x, task = blockIdx.x;
+    const int group = task % a.num_groups;
+    const int total = m.queue_cnt[task];
+    if (total <= 0 || total > m.queue_cap || m.fallback[group]) return;
+    const unsigned long long *queue = m.queue + (size_t)task * m.queue_cap;
+    const float4 *V4 = reinterpret_cast<const float4 *>(Vp);
+    const int64_t v4_end = (int64_t)a.total_clips * ROW4;
+    float4 pre[NLD], preq[NLQ];
+    auto gload = [&](int c0) {                                           // NT rows from clip c0 (clamped at the end of V)
+#pragma unroll
+        for (int t = 0; t < NLD; ++t) {
+            const int idx = lane + 64 * t;
+            const int64_t g4 = (int64_t)c0 * ROW4 + idx;
+            pre[t] = (idx < NT * ROW4 && g4 < v4_end) ? V4[g4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int t = 0; t < NLD; ++t) {
+            const int idx = lane + 64 * t;
+            if (idx < NT * ROW4) reinterpret_cast<float4 *>(vst)[idx] = pre[t];
+        }
+    };
+    const float2v e2 = {a.eps, a.eps};
+    for (int base = 0; base < total; base += 64) {
+        const int nb = total - base < 64 ? total - base : 64;
+        const bool have = lane < nb;
+        const unsigned long long ent = queue[base + (have ? lane : nb - 1)];
+        const int64_t qi = (int64_t)(ent >> 32);
+        const int v = (int)((ent >> 2) & 0x3FFFFFFFu);
+        const unsigned rmask = have ? (unsigned)(ent & 3u) : 0u;
+        const int qlo = (int)qi;                                         // (query index < 2^31)
+        auto gload_q = [&](int first, int rows) {                        // query rows of pairs [first, first + rows) -> registers
+#pragma unroll
+            for (int t = 0; t < NLQ; ++t) {
+                const int idx = lane + 64 * t, rr = idx / ROW4, j4 = idx - rr * ROW4;
+                const int src = __shfl(qlo, first + (rr < rows ? rr : 0), 64);
+                preq[t] = rr < rows ? reinterpret_cast<const float4 *>(Qp + (int64_t)src * FAST_D)[j4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto swrite_q = [&]() {
+#pragma unroll
+            for (int t = 0; t < NLQ; ++t) {
+                const int idx = lane + 64 * t;
+                if (idx < QR * ROW4) reinterpret_cast<float4 *>(qst)[idx] = preq[t];
+            }
+        };
+        auto run_at = [&](int at) -> int {                               // consecutive pairs of the video of pair `at`, <= QR
+            const int vv = __builtin_amdgcn_readlane(v, at);
+            const unsigned long long same = __ballot(v == vv) >> at;
+            int run = same == ~0ull ? 64 - at : __builtin_ctzll(~same);
+            run = run < nb - at ? run : nb - at;
+            return run < QR ? run : QR;
+        };
+        // ---- phase 1 ----
+        int idx = 0, run = run_at(0);
+        gload(clip_off[__builtin_amdgcn_readlane(v, 0)]);
+        gload_q(0, run);
+        while (idx < nb) {
+            const int vv = __builtin_amdgcn_readlane(v, idx);
+            const int c0 = clip_off[vv], n = clip_off[vv + 1] - c0;
+            (void)c0;
+            __builtin_amdgcn_s_waitcnt(0xC07F);                         // earlier LDS reads of vst / qst are done (one wave: in order)
+            swrite();
+            swrite_q();
+            const int nxt = idx + run;
+            int run_n = 0;
+            if (nxt < nb) {                                              // next run's rows in flight under this run's chains
+                run_n = run_at(nxt);
+                gload(clip_off[__builtin_amdgcn_readlane(v, nxt)]);
+                gload_q(nxt, run_n);
+            }
+            const int chains = run * n;
+            for (int cb = 0; cb < chains; cb += 64) {
+                const int id = cb + lane;
+                const bool on = id < chains;
+                const int pl = on ? id / n : 0, c = on ? id - pl * n : 0;
+                const float4 *q4 = reinterpret_cast<const float4 *>(qst + pl * FAST_D);
+                const float4 *v4 = reinterpret_cast<const float4 *>(vst + c * FAST_D);
+                float acc = 0.0f;
+#ifdef VFR_PAIRS_SKIP_CHAIN
+                acc = v4[lane & 15].x + q4[lane & 7].y;                  // timing experiment: no chain
+#else
+#pragma unroll 5
+                for (int j4 = 0; j4 < ROW4; ++j4) {
+                    const float4 x = v4[j4], y = q4[j4];
+                    const float2v d01 = (float2v{x.x, x.y} - float2v{y.x, y.y}) + e2;
+                    const float2v d23 = (float2v{x.z, x.w} - float2v{y.z, y.w}) + e2;
+                    acc = __builtin_fmaf(d01.x, d01.x, acc);
+                    acc = __builtin_fmaf(d01.y, d01.y, acc);
+                    acc = __builtin_fmaf(d23.x, d23.x, acc);
+                    acc = __builtin_fmaf(d23.y, d23.y, acc);
+                }
+#endif
+                if (on) dx[(idx + pl) * NT + c] = __builtin_sqrtf(acc);
+            }
+            idx = nxt;
+            run = run_n;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#ifdef VFR_PAIRS_SKIP_P2
+        if (dx[lane] == 123.456f) atomicAdd(m.cnt_ws + qi, 1ull);      // timing experiment: no triangle
+        continue;
+#endif
+        // ---- phase 2 ----
+        const int c0 = clip_off[v], n = clip_off[v + 1] - c0;
+        const int64_t mbase = mom_off[v];
+        float d[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) d[c] = (have && c < n) ? dx[lane * NT + c] : __builtin_inff();
+        int cntr[NR] = {0};
+        float sums[NT];
+        const unsigned *tq = m.tab + (qi * NR) * NT * MF_TAB;
+        bool tie = false;
+        // every lane's bounds come from a different query's table rows: all of them requested at once (one memory round trip
+        // for the batch instead of one per span length)
+        uint2 bnd[NR][NT];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int L = 1; L <= NT; ++L) bnd[r][L - 1] = *reinterpret_cast<const uint2 *>(tq + (r * NT + (L - 1)) * MF_TAB);
+#pragma unroll
+        for (int L = 1; L <= NT; ++L) {
+#pragma unroll
+            for (int s = 0; s + L <= NT; ++s) {
+                const float de = d[s + L - 1];
+                const float sum = L == 1 ? de : sums[s] + de;
+                sums[s] = sum;
+                const unsigned sb = __float_as_uint(sum);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    cntr[r] += sb < bnd[r][L - 1].x ? 1 : 0;
+                    tie = tie || (sb >= bnd[r][L - 1].x && sb < bnd[r][L - 1].y);
+                }
+            }
+        }
+        if (__ballot(tie && rmask != 0u)) {
+            // score == a rank key somewhere: walk this lane's video once more with the exact division and break ties by id
+            if (tie) {
+#pragma nounroll
+                for (int s = 0; s < n; ++s) {
+                    float sum = 0.0f;
+#pragma nounroll
+                    for (int e = s; e < n; ++e) {
+                        const float de = dx[lane * NT + e];
+                        sum = e == s ? de : sum + de;
+                        const float sc = sum / (float)(e - s + 1);
+                        const unsigned id = (unsigned)(a.id_base + mbase + moment_index(n, s, e));
+#pragma unroll
+                        for (int r = 0; r < NR; ++r)
+                            if (sc == rank_dist[r * a.Nq + qi] && id < (unsigned)rank_idx[r * a.Nq + qi]) cntr[r] += 1;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (((rmask >> r) & 1u) && cntr[r]) atomicAdd(m.cnt_ws + r * a.Nq + qi, (unsigned long long)cntr[r]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                             // dx is rewritten by the next batch
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// finisher: one wave per query.  The k' approximate candidates (sorted keys, KEY_MAX padded) are re-scored with the
+// canonical chain, sorted by exact (score, id) and the k best written out; the containment condition of the header is
+// checked on the approximate keys and a failing query flags its group for the exact kernels.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KPL>
+__global__ __launch_bounds__(256) void topk_finish_kernel(const unsigned long long *__restrict__ cand, int kp, int k,
+                                                          const float *__restrict__ Q, int64_t Nq, const float *__restrict__ V,
+                                                          const int32_t *__restrict__ clip_off, const int64_t *__restrict__ mom_off,
+                                                          int Nv, int uniform_n, int D, float eps, int64_t id_base,
+                                                          const float4 *__restrict__ qmeta, int *__restrict__ fallback,
+                                                          const int64_t *__restrict__ thr_seed, float *__restrict__ out_dist,
+                                                          int64_t *__restrict__ out_idx, int check)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wv;
+    if (q >= Nq) return;
+    const float *qr = Q + q * D;
+    unsigned long long key[KPL];
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const int e = i * 64 + lane;
+        key[i] = KEY_MAX;
+        const unsigned long long ak = e < kp ? cand[q * kp + e] : KEY_MAX;
+        if (ak == KEY_MAX) continue;
+        const unsigned local = (unsigned)(ak & 0xffffffffull) - (unsigned)id_base;
+        int v, mloc, n;
+        if (uniform_n > 0) {
+            n = uniform_n;
+            const unsigned M = (unsigned)(n * (n + 1) / 2);
+            v = (int)(local / M);
+            mloc = (int)(local - (unsigned)v * M);
+        } else {
+            int lo = 0, hi = Nv;                                        // largest v with mom_off[v] <= local
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (mom_off[mid] <= (int64_t)local) lo = mid; else hi = mid; }
+            v = lo;
+            mloc = (int)((int64_t)local - mom_off[v]);
+            n = clip_off[v + 1] - clip_off[v];
+        }
+        int s = mloc, e2 = mloc;
+        if (mloc >= n) {
+            int rest = mloc - n;
+            s = 0;
+            while (rest >= n - 1 - s) { rest -= n - 1 - s; ++s; }
+            e2 = s + 1 + rest;
+        }
+        const int c0 = clip_off[v];
+        float sum = 0.0f;
+        for (int c = s; c <= e2; ++c) {
+            const float *vr = V + (int64_t)(c0 + c) * D;
+            float acc = 0.0f;
+            for (int kk = 0; kk < D; ++kk) {
+                const float dd = (vr[kk] - qr[kk]) + eps;
+                acc = __builtin_fmaf(dd, dd, acc);
+            }
+            const float dc = __builtin_sqrtf(acc);
+            sum = c == s ? dc : sum + dc;
+        }
+        key[i] = make_key(sum / (float)(e2 - s + 1), (unsigned)(ak & 0xffffffffull));
+    }
+    if (check) {
+        // containment: s~_(k') > s~_(k) + 2 delta with delta = E2 / s~_(1) + (58 + 2 L) u s~  (L <= 64), or a short list
+        const unsigned long long a1 = cand[q * kp], ak = k - 1 < kp ? cand[q * kp + (k - 1)] : KEY_MAX, aK = cand[q * kp + kp - 1];
+        if (aK != KEY_MAX && ak != KEY_MAX) {
+            const float s1 = __uint_as_float((unsigned)(a1 >> 32)), sk = __uint_as_float((unsigned)(ak >> 32)),
+                        sK = __uint_as_float((unsigned)(aK >> 32));
+            const float E2 = qmeta[q].z;
+            const float delta = (s1 > 0.0f ? E2 / s1 : __builtin_inff()) + 190.0f * MF_U * sK * 1.02f;
+            if (!(sK > sk + 2.0f * delta * 1.0001f) && lane == 0) fallback[q >> 6] = 1;
+        }
+        if (thr_seed && a1 != KEY_MAX) {
+            // a seeded pass took its threshold margin for clips no closer than half the seed score (mfma_seed_kernel)
+            const unsigned long long sd = (unsigned long long)thr_seed[q];
+            const float x = __uint_as_float((unsigned)(sd >> 32)), s1 = __uint_as_float((unsigned)(a1 >> 32));
+            if (sd < KEY_EMPTY && x < __builtin_inff() && !(s1 >= 0.5f * x) && lane == 0) fallback[q >> 6] = 1;
+        }
+    }
+    wave_sort<KPL>(key, lane);
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const int e = i * 64 + lane;
+        if (e < k) {
+            const bool ok = key[i] != KEY_MAX;
+            out_dist[q * k + e] = ok ? __uint_as_float((unsigned)(key[i] >> 32)) : __builtin_inff();
+            out_idx[q * k + e] = ok ? (int64_t)(key[i] & 0xffffffffull) : -1;
+        }
+    }
+}
+
+// count_lt += the call's counts, for the query groups the approximate path answered
+__global__ __launch_bounds__(256) void mfma_commit_counts_kernel(const unsigned long long *__restrict__ cnt_ws, int NR,
+                                                                 int64_t Nq, const int *__restrict__ fallback,
+                                                                 int64_t *__restrict__ count_lt)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)NR * Nq) return;
+    const int64_t q = i % Nq;
+    if (fallback && fallback[q >> 6]) return;
+    count_lt[i] += (int64_t)cnt_ws[i];
+}

@@ -127,7 +127,7 @@ const char *vfr_profile_site_name(int site)
     static const char *names[vfr::SITE_COUNT] = {
         "none", "gemm_vis_seg", "gemm_vis_ctx", "vis_hidden", "gemm_vis_out", "embed", "gemm_lstm_in", "gemm_lstm_rec",
         "lstm_pointwise", "gemm_lang_fc", "score_fused", "topk_merge", "score_dense", "score_own", "pool", "linear",
-        "conv3x3", "pool2d", "normalize", "score_rank", "score_prepass", "repack", "exchange"};
+        "conv3x3", "pool2d", "normalize", "score_rank", "score_prepass", "repack", "exchange", "score_prep", "score_pairs", "score_finish", "score_fallback"};
     return site >= 0 && site < vfr::SITE_COUNT ? names[site] : "?";
 }
 

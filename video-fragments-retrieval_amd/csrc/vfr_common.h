@@ -35,7 +35,7 @@ enum Site : int {
     SITE_EMBED, SITE_GEMM_LSTM_IN, SITE_GEMM_LSTM_REC, SITE_LSTM_POINTWISE, SITE_GEMM_LANG_FC,
     SITE_SCORE_FUSED, SITE_TOPK_MERGE, SITE_SCORE_DENSE, SITE_SCORE_OWN, SITE_POOL, SITE_LINEAR,
     SITE_CONV, SITE_POOL2D, SITE_NORMALIZE, SITE_SCORE_RANK, SITE_SCORE_PREPASS, SITE_REPACK,
-    SITE_EXCHANGE,
+    SITE_EXCHANGE, SITE_SCORE_PREP, SITE_SCORE_PAIRS, SITE_SCORE_FINISH, SITE_SCORE_FALLBACK,
     SITE_COUNT
 };
 bool profiling();

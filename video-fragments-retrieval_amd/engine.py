@@ -28,10 +28,11 @@ KEY_INF = (0x7F800000 << 32) | 0xFFFFFFFF      # key of (+inf, max id): "no grou
 class HipOps:
     """Device arithmetic through the C ABI (``_vfr``).  Raises if libvfr.so or the GPU is missing."""
 
-    def __init__(self):
+    def __init__(self, score_mode=None):
         from . import _vfr
         _vfr.lib()
         self.v = _vfr
+        self.score_mode = score_mode          # None: _vfr.DEFAULT_SCORE_MODE ("mfma": MFMA pre-filter, exact results)
 
     def make_bank(self, emb, clip_off, id_base):
         return self.v.VideoBank(emb, clip_off, id_base)
@@ -47,7 +48,7 @@ class HipOps:
 
     def score_topk(self, Q, bank, k, rank_dist, rank_idx, workspace=None, count_lt=None, thr_seed=None):
         return self.v.score_topk(Q, bank, k, rank_dist, rank_idx, count_lt=count_lt, workspace=workspace,
-                                 thr_seed=thr_seed)
+                                 thr_seed=thr_seed, mode=self.score_mode)
 
     def slice_bank(self, bank, counts, v0, v1):
         return self.v.slice_bank(bank, counts, v0, v1)
