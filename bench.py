@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--feat-dim", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bf16 / small-batch / VGG sub-records measured after the timed steps")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="vfr_set_option passthrough for parameter sweeps (results must not change: compare the checksums)")
     ap.add_argument("--host-feed", action="store_true",
@@ -56,31 +57,46 @@ def parse():
     return ap.parse_args()
 
 
+# profiler sites -> the kernel they launch (the dominant kernel is chosen per KERNEL: the scorer's ladder stages B and C
+# are the same kernel under two sites)
+KERNEL_OF_SITE = {
+    "gemm_lstm_rec": "lstm_step_mfma_pair", "gemm_vis_seg": "gemm_nt_mfma<seg+hidden>", "gemm_vis_ctx": "gemm_nt_mfma<ctx>",
+    "gemm_vis_out": "gemm_nt_mfma<out>", "gemm_lang_fc": "gemm_nt_mfma<lang_fc>", "gemm_lstm_in": "gemm_nt_mfma<vocab projection>",
+    "score_fused": "score_mfma_kernel", "score_prepass": "score_mfma_kernel", "score_rank": "score_mfma_kernel",
+    "score_pairs": "score_pairs_exact_kernel", "score_finish": "topk_finish_kernel", "score_prep": "mfma_prep kernels",
+    "score_fallback": "score_fast_kernel (masked fallback)", "topk_merge": "topk_merge_tasks_kernel", "score_own": "score_own_kernel",
+    "exchange": "exchange / label kernels",
+}
+SCORER_SITES = ("score_fused", "score_prepass", "score_rank", "score_pairs", "score_finish", "score_prep", "score_fallback", "topk_merge")
+
+
 def site_work(site, cfg):
-    """Algorithmic FLOP per launch of an instrumented site (SURVEY.md 8d figures), and which roof bounds it."""
-    B, C, Nv, H, E, F, hid, D, n, Nq = (cfg[k] for k in ("Bq", "C", "Nv", "H", "E", "F", "hid", "D", "n", "Nq"))
+    """(algorithmic FLOP per launch -- SURVEY.md 8d figures x the units one launch processes --, FLOP the kernel actually
+    executes per launch) of an instrumented site.  They differ for the fused LSTM step: the reference's arithmetic has an
+    E-wide input part per (query, time) which the kernel reads from the per-vocabulary projection table instead of
+    multiplying, and the first step's recurrent part (h_0 = 0) is skipped."""
+    B, C, Nv, H, E, F, hid, D, n, Nq, T, vocab = (cfg[k] for k in ("Bq", "C", "Nv", "H", "E", "F", "hid", "D", "n", "Nq", "T", "vocab"))
     M = n * (n + 1) // 2
-    # threshold ladder of the top-k pass (score.hip: PRE_VIDEOS, PRE_LEVELS, pre_b_videos): stage A = the 1- and 2-clip moments of
-    # 64 videos (its work is not counted: the sample is scored again in full by stage B), stage B = Nv/16 <= 640 videos
-    nb = min(640, Nv // 16) if Nv >= 256 else 0
+    nb = min(640, Nv // 16) if Nv >= 256 else 0          # ladder stage B (score.hip: pre_b_videos)
+    rows = cfg["lstm_rows_per_step"]
+    per_scoring = 2 * n * D + n + 2 * M
     table = {
-        # fused step [x_t | h] x [Wih | Whh]^T; rows actually processed per launch, averaged over the T steps: the
-        # forward direction steps every query (+1 all-pad row), the reverse direction only the queries that have
-        # reached a real token (their trailing-pad prefix is shared through the all-pad row)
-        "gemm_lstm_rec": 2.0 * cfg["lstm_rows_per_step"] * 4 * H * (E + H),
-        "gemm_lstm_in": 2.0 * 2 * B * 4 * H * E,
-        "gemm_vis_seg": 2.0 * C * hid * F,
-        "gemm_vis_ctx": 2.0 * Nv * hid * F,
-        "gemm_vis_out": 2.0 * C * D * hid,
-        "gemm_lang_fc": 2.0 * B * D * 2 * H,
-        # scoring launches (SURVEY 8d: 2nD contraction + n norms + 2M moment means per scoring).  With top-k the first
-        # Nv/16 (<= 640) videos are stage B of the threshold ladder (site score_prepass, together with stage A's short-moment
-        # pass over 32 of them); the main fused launch (top-k + rank keys, one distance pass) covers the rest.
-        "score_fused": float(Nq) * max(Nv - nb, 0) * (2 * n * D + n + 2 * M),
-        "score_rank": float(Nq) * Nv * (2 * n * D + n + 2 * M),          # k = 0 calls only
-        "score_prepass": float(Nq) * nb / 2 * (2 * n * D + n + 2 * M),   # two launches (A, B); B's work averaged over both
+        # fused step [x_t | h] x [Wih | Whh]^T over the rows processed per launch (forward: every query + the all-pad row;
+        # reverse: only the queries that have reached a real token), averaged over the T launches
+        "gemm_lstm_rec": (2.0 * rows * 4 * H * (E + H), 2.0 * rows * 4 * H * H * (T - 1) / T),
+        # emb x W_ih^T for both directions, once per VOCABULARY entry (not per query)
+        "gemm_lstm_in": (2.0 * 2 * vocab * 4 * H * E,) * 2,
+        "gemm_vis_seg": (2.0 * C * hid * F,) * 2,
+        "gemm_vis_ctx": (2.0 * Nv * hid * F,) * 2,
+        "gemm_vis_out": (2.0 * C * D * hid,) * 2,
+        "gemm_lang_fc": (2.0 * B * D * 2 * H,) * 2,
+        # scoring launches (SURVEY 8d: 2nD contraction + n norms + 2M moment means per scoring): stage B of the threshold
+        # ladder = the first Nv/16 (<= 640) videos, the main launch the rest (stage A's 64-video sample is scored again by B)
+        "score_fused": (float(Nq) * max(Nv - nb, 0) * per_scoring,) * 2,
+        "score_rank": (float(Nq) * Nv * per_scoring,) * 2,
+        "score_prepass": (float(Nq) * nb / 2 * per_scoring,) * 2,
     }
-    return table.get(site)
+    return table.get(site, (None, None))
 
 
 def cpu_baseline(args, n_clips):
@@ -179,7 +195,7 @@ def main():
 
     with torch.no_grad():
         gt_idx = engine.gt_index(make_shard(model.encode_clips(seg, ctx, clip_off)), own)    # which queries this shard owns
-    ws = _vfr.topk_workspace(Nq, hi - lo, args.k, dev)
+    ws = _vfr.topk_workspace(Nq, hi - lo, args.k, dev, total_clips=C_loc)
 
     def ranks_of(shard, Q):
         # a11 inside the step: the label table of the batch (model/evaluate.py:59-65) is rebuilt from the spans every pass
@@ -187,13 +203,28 @@ def main():
         gt = engine.prepare_gt(shard, own, labels, index=gt_idx)
         return engine.corpus_ranks(shard, Q, own, labels, ops, k=args.k, world=world, workspace=ws, gt=gt)
 
+    def subset(nq):                                   # the same pass for the first nq queries (small-batch sub-records)
+        idx = engine.gt_index(make_shard(torch.empty((C_loc, 100), device=dev)), own[:nq])
+        td = (times_dev[0][:nq].contiguous(), times_dev[1][:nq].contiguous())
+        nd = n_own_dev[:nq].contiguous()
+
+        def run(shard, Q):
+            labels = ops.gt_labels(td, nd, IOU, True, dev, Mmax=Mmax_own)
+            gt = engine.prepare_gt(shard, own[:nq], labels, index=idx)
+            return engine.corpus_ranks(shard, Q, own[:nq], labels, ops, k=args.k, world=1, workspace=ws, gt=gt)
+        return run
+    ranks_of.own, ranks_of.subset = own, subset
+
+    state = {}
+
     def step():
         with torch.no_grad():
             # a rank's two encoders are small enough from N = 4 on to leave CUs idle in their partial tile rounds: run them side
             # by side there (tools/rank_sim.py: -0.16 ms at 8, -0.09 at 4, +0.08 at 2); below they stay back to back (the per-kernel durations quoted in `roofline` are then undisturbed)
             emb, Q = engine.overlapped(dev, lambda: model.encode_clips(seg, ctx, clip_off),
                                        lambda: engine.encode_queries(model, tokens, dev, ops, rank, world), enable=world >= 4)
-            return ranks_of(make_shard(emb), Q)
+            state["shard"] = make_shard(emb)
+            return ranks_of(state["shard"], Q)
 
     def barrier():
         if dist is not None:
@@ -262,50 +293,158 @@ def main():
     qlen = np.where(tok0 != 0, np.arange(1, T_ + 1)[None, :], 0).max(axis=1)
     rev_rows = sum(1 + int((qlen > T_ - 1 - s).sum()) for s in range(T_)) / T_
     cfg = dict(Bq=Bq, C=C_loc, Nv=hi - lo, H=model.hidden_size, E=100, F=F, hid=500, D=100,
-               n=int(round(n_eff)), Nq=Nq, T=T_, lstm_rows_per_step=(Bq + 1) + rev_rows)
+               n=int(round(n_eff)), Nq=Nq, T=T_, lstm_rows_per_step=(Bq + 1) + rev_rows,
+               vocab=int(sd["word_embedding.weight"].shape[0]))
     if not sites:                                  # VFR_BENCH_NO_SITES rehearsal: nothing to attribute
         print(json.dumps({"ms_per_step": ms_step, "value": value, "n_gpus": world, "note": "site events off (rehearsal)"}))
         if dist is not None:
             dist.destroy_process_group()
         return
-    kernels, dom, dom_ms = {}, None, -1.0
+    kernels, per_kernel = {}, {}
     for name, (ms, cnt) in sites.items():
-        fl = site_work(name, cfg)
-        kernels[name] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps,
-                         "tflops": (fl * cnt / (ms * 1e-3) / 1e12) if fl else None}
-        if ms > dom_ms:
-            dom, dom_ms = name, ms
-    dom_ms_launch = dom_ms / sites[dom][1]
-    fl = site_work(dom, cfg)
-    achieved = fl / (dom_ms_launch * 1e-3) / 1e12 if fl else None
-    traffic = None                      # HBM bytes/launch of this kernel from the committed PMC passes (profiles/README.md)
+        fl, fl_exec = site_work(name, cfg)
+        tf = (fl * cnt / (ms * 1e-3) / 1e12) if fl else None
+        tf_exec = (fl_exec * cnt / (ms * 1e-3) / 1e12) if fl_exec else None
+        # no site may claim more than the chip can do: a violation is an accounting bug, not a result
+        assert tf is None or tf <= FP32_PEAK_TFLOPS, f"site {name}: {tf:.1f} TFLOP/s > fp32 peak -- wrong work formula"
+        kernels[name] = {"kernel": KERNEL_OF_SITE.get(name, name), "ms_per_step": ms / args.steps,
+                         "launches_per_step": cnt / args.steps, "tflops": tf, "tflops_executed": tf_exec}
+        k = per_kernel.setdefault(KERNEL_OF_SITE.get(name, name), {"ms": 0.0, "launches": 0, "flop": 0.0, "flop_exec": 0.0, "sites": []})
+        k["ms"] += ms; k["launches"] += cnt; k["sites"].append(name)
+        k["flop"] += (fl or 0.0) * cnt; k["flop_exec"] += (fl_exec or 0.0) * cnt
+    # dominant kernel = largest share of device time, per KERNEL (a kernel launched from two sites counts once)
+    dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
+    pk = per_kernel[dom]
+    dom_ms_launch = pk["ms"] / pk["launches"]
+    achieved = pk["flop"] / (pk["ms"] * 1e-3) / 1e12 if pk["flop"] else None
+    executed = pk["flop_exec"] / (pk["ms"] * 1e-3) / 1e12 if pk["flop_exec"] else None
+    # HBM bytes per launch of this kernel: NOT measured in this run -- quoted from the committed PMC passes of the same
+    # kernel (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 FETCH_SIZE x2 correction; profiles/README.md)
+    traffic, traffic_src = None, None
     tfile = ROOT / "profiles" / "traffic_latest.json"
     if tfile.exists():
-        traffic = json.loads(tfile.read_text()).get(dom)
-    roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": (achieved / FP32_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
-                "avg_launch_ms": dom_ms_launch, "launches_per_step": sites[dom][1] / args.steps,
-                "share_of_step": dom_ms / args.steps / ms_step}
+        tj = json.loads(tfile.read_text())
+        for site_name in pk["sites"]:
+            if tj.get(site_name) is not None:
+                traffic, traffic_src = tj[site_name], tj.get("_source", "profiles/traffic_latest.json (committed PMC passes, not this run)")
+                break
+    roofline = {"kernel": dom, "sites": pk["sites"], "bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": (achieved / FP32_PEAK_TFLOPS) if achieved else None,
+                "achieved_executed": executed, "frac_executed": (executed / FP32_PEAK_TFLOPS) if executed else None,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": dom_ms_launch, "launches_per_step": pk["launches"] / args.steps,
+                "share_of_step": pk["ms"] / args.steps / ms_step}
+    # the scorer as a whole (all its kernels): algorithmic scoring FLOP of the pass / their summed device time
+    sc_ms = sum(sites[s_][0] for s_ in SCORER_SITES if s_ in sites) / args.steps
+    sc_flop = float(Nq) * (hi - lo) * (2 * cfg["n"] * 100 + cfg["n"] + cfg["n"] * (cfg["n"] + 1))
+    scorer = {"mode": _vfr.DEFAULT_SCORE_MODE, "ms_per_step": sc_ms, "tflops": sc_flop / (sc_ms * 1e-3) / 1e12 if sc_ms else None,
+              "frac_fp32_peak": sc_flop / (sc_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS if sc_ms else None,
+              "sites_ms": {s_: sites[s_][0] / args.steps for s_ in SCORER_SITES if s_ in sites}}
+    if world == 1 and _vfr.DEFAULT_SCORE_MODE == "mfma":
+        scorer["exact_rescoring"] = _vfr.score_mfma_stats(ws, Nq, state["shard"].bank, args.k)
     line = {
         "metric": "query x video scorings/sec, full evaluate pass (clip MLP + BiLSTM + moment scoring/top-k/rank), DiDeMo-shape",
         "value": value, "unit": "scorings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"BASELINE config 1: {Nv} videos x {args.clips} clips x {F}-d fc7 features, {Nq}-query batch, "
-                               f"top-{args.k} + rank@IoU{{0.5,0.7}}, fp32, videos sharded over {world} GPU(s)",
+                               f"ground-truth labels + top-{args.k} + rank@IoU{{0.5,0.7}}, fp32, videos sharded over {world} GPU(s)",
                    "videos": Nv, "clips": args.clips, "queries": Nq, "k": args.k, "parallelism": f"shard{world}"},
         "gpu_event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
         "median_rank_check": float(ranks[0].float().median()),
         "ranks_checksum": int(ranks.sum()), "topk_checksum": int(out[2].sum()) if out[2] is not None else None,
-        "roofline": roofline, "kernels": kernels,
+        "roofline": roofline, "scorer": scorer, "kernels": kernels,
     }
     if host_feed is not None:
         line["pcie_inclusive"] = host_feed
+    if world == 1 and not args.no_extras:
+        line.update(extras(args, dev, model, seg, ctx, clip_off, tokens, make_shard, ranks_of, out, Nq, Nv, counts_all, ops))
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, n_clips)
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps, r
+
+
+def extras(args, dev, model, seg, ctx, clip_off, tokens, make_shard, ranks_of, out_f32, Nq, Nv, counts_all, ops):
+    """Sub-records measured after the timed region (never part of `value`): BASELINE config 5 (bf16 MFMA scoring, tolerance
+    against the fp32 result), the small query batches of config 2, and config 3's VGG19-fc7 extractor."""
+    from vfr_amd import _vfr, engine, synth
+    ex = {}
+    with torch.no_grad():
+        emb = model.encode_clips(seg, ctx, clip_off)
+        shard = make_shard(emb)
+        Q = engine.encode_queries(model, tokens, dev, ops)
+        # ---- bf16 operands, fp32 accumulate (config 5): the same step with the scoring in bf16 mode ----
+        old = _vfr.DEFAULT_SCORE_MODE
+        try:
+            _vfr.DEFAULT_SCORE_MODE = "bf16"
+            dt_sc, out_b = _timed(lambda: ranks_of(shard, Q), 3)
+            _vfr.DEFAULT_SCORE_MODE = old
+            dt_f32, _ = _timed(lambda: ranks_of(shard, Q), 3)
+        finally:
+            _vfr.DEFAULT_SCORE_MODE = old
+        r_f, _, i_f = out_f32
+        r_b, _, i_b = out_b
+        k = i_f.shape[1]
+        same10 = (i_f[:, :10, None] == i_b[:, None, :10]).any(-1).float().mean()
+        samek = (i_f[:, :, None] == i_b[:, None, :]).any(-1).float().mean()
+        total_m = float(int(counts_all.astype(np.int64) @ (counts_all.astype(np.int64) + 1)) // 2)
+        ex["bf16"] = {"what": "scoring with bf16 MFMA operands / fp32 accumulate (vfr_score_topk_mfma dtype bf16): rank counts from the "
+                              "bf16 distances, top-k = exact re-rank of the k + 28 best bf16 candidates; same encoders (fp32)",
+                      "scoring_ms": dt_sc * 1e3, "scoring_ms_f32_mode": dt_f32 * 1e3,
+                      "scorings_per_s_scoring_only": Nq * Nv / dt_sc,
+                      "rank1_agreement": float((i_f[:, 0] == i_b[:, 0]).float().mean()),
+                      "top10_overlap": float(same10), f"top{k}_overlap": float(samek),
+                      "rank_count_max_abs_diff_over_moments": float((r_f - r_b).abs().max()) / total_m,
+                      "R@1_R@10_R@100_f32": [float((r_f[0] < t).float().mean()) for t in (1, 10, 100)],
+                      "R@1_R@10_R@100_bf16": [float((r_b[0] < t).float().mean()) for t in (1, 10, 100)],
+                      "median_rank_f32_vs_bf16": [float(r_f[0].float().median()), float(r_b[0].float().median())]}
+        # ---- small query batches (BASELINE config 2: Nq in {1, 64, 1024}): query encoder + labels + scoring against the
+        # resident clip bank (what a serving request costs once the corpus is embedded)
+        small = {}
+        for nq in (1, 64, 1024):
+            if nq > Nq:
+                continue
+            tk = tokens[:nq].contiguous()
+            own_s = np.asarray(ranks_of.own[:nq])
+            sub = ranks_of.subset(nq)
+            dt_q, _ = _timed(lambda: sub(shard, engine.encode_queries(model, tk, dev, ops)), 5)
+            small[str(nq)] = {"ms": dt_q * 1e3, "scorings_per_s": nq * Nv / dt_q}
+        ex["small_batches"] = {"what": "query encoder + labels + fused scoring of Nq queries against the resident clip bank", **small}
+    # ---- VGG19-fc7 extractor (config 3): one 150-frame video of 224x224 frames, full-width random weights ----
+    try:
+        cfgv = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+        g = torch.Generator(device=dev); g.manual_seed(7)
+        cw, cb, cin = [], [], 3
+        for c in cfgv:
+            if c == "M":
+                continue
+            cw.append(torch.randn((c, cin, 3, 3), device=dev, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+            cb.append(torch.zeros(c, device=dev))
+            cin = c
+        fc6 = (torch.randn((4096, 512 * 49), device=dev, generator=g) * 0.01, torch.zeros(4096, device=dev))
+        fc7 = (torch.randn((4096, 4096), device=dev, generator=g) * 0.01, torch.zeros(4096, device=dev))
+        frames = torch.randint(0, 256, (150, 224, 224, 3), device=dev, dtype=torch.uint8, generator=g)
+        dt_v, feat = _timed(lambda: _vfr.vgg_fc7(frames, cfgv, cw, cb, fc6, fc7), 2)
+        gflop = 39.26 * 150
+        ex["vgg"] = {"what": "get_rgb_features.py path: 150 uint8 frames 224x224x3 -> VGG19 fc7 [150, 4096], fp32, random full-width weights",
+                     "ms_per_video": dt_v * 1e3, "frames_per_s": 150 / dt_v, "videos_per_s": 1 / dt_v,
+                     "tflops": gflop / dt_v / 1e3, "frac_fp32_mfma_peak": gflop / dt_v / 1e3 / FP32_PEAK_TFLOPS,
+                     "finite": bool(torch.isfinite(feat).all())}
+    except RuntimeError as e:                                   # e.g. out of memory on a shared device: report, do not hide
+        ex["vgg"] = {"error": str(e)[:200]}
+    return ex
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ OUTPUTS plus the recipe parameters; tests regenerate the inputs from the same se
 
 Fixtures:  G1 encoders, G2 scoring + both evaluate() dicts (n=6, n=21, ragged 5/6),
 G3 generate_moments / get_iou, G4 load_video_features pooling, G5 tokeniser + WordIndexer, G6 validate_epoch,
-G7 ranking loss, G8 evaluate() with the 'chance' baseline.
+G7 ranking loss, G8 evaluate() with the 'chance' baseline, G9 one full-size VGG-19 frame through torch.nn modules.
 """
 import json
 import random
@@ -322,6 +322,40 @@ def g8_chance(nv=40, nq=130, feat_dim=256):
     print("G8", out)
 
 
+def g9_vgg_full():
+    """a2 at FULL size: one 224x224 frame through the VGG-19 "E" stack built from torch.nn modules (the layers
+    torchvision.models.vgg19 is made of -- get_rgb_features.py:122-126 truncates its classifier to [0..4]; torchvision itself
+    is absent here, so this pins the composition, not torchvision's file), seeded full-width weights, fc 4096."""
+    import torch.nn as nn
+    cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+    cw, cb, fc6, fc7 = synth.vgg_weights(cfg, (224, 224), 4096, seed=5)
+    frames = synth.frames_u8(1, 224, 224, seed=5)
+    layers, cin, i = [], 3, 0
+    for item in cfg:
+        if item == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            conv = nn.Conv2d(cin, item, kernel_size=3, padding=1)
+            conv.weight.data.copy_(torch.from_numpy(cw[i])); conv.bias.data.copy_(torch.from_numpy(cb[i]))
+            layers += [conv, nn.ReLU(inplace=True)]
+            cin, i = item, i + 1
+    features = nn.Sequential(*layers)
+    avgpool = nn.AdaptiveAvgPool2d((7, 7))
+    l6, l7 = nn.Linear(512 * 49, 4096), nn.Linear(4096, 4096)
+    l6.weight.data.copy_(torch.from_numpy(fc6[0])); l6.bias.data.copy_(torch.from_numpy(fc6[1]))
+    l7.weight.data.copy_(torch.from_numpy(fc7[0])); l7.bias.data.copy_(torch.from_numpy(fc7[1]))
+    classifier = nn.Sequential(l6, nn.ReLU(True), nn.Dropout(), l7, nn.ReLU(True))          # vgg19.classifier[0..4]
+    model = nn.Sequential(features, avgpool, nn.Flatten(1), classifier).eval()
+    mean = torch.tensor([0.485, 0.456, 0.406])
+    std = torch.tensor([0.229, 0.224, 0.225])
+    x = torch.from_numpy(frames).transpose(3, 1).transpose(2, 3).float().div(255)                 # get_rgb_features.py:64-69
+    x = x.sub(mean[None, :, None, None]).div(std[None, :, None, None])
+    with torch.no_grad():
+        out = model(x).numpy()
+    np.savez_compressed(OUT / "g9_vgg_full.npz", fc7=out.astype(np.float32))
+    print("G9", out.shape, float(out.max()), float(out.mean()))
+
+
 if __name__ == "__main__":
     g3_moments_iou()
     g5_tokens()
@@ -333,3 +367,4 @@ if __name__ == "__main__":
     g6_validate_epoch()
     g7_ranking_loss()
     g8_chance()
+    g9_vgg_full()

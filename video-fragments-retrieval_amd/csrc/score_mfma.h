@@ -360,6 +360,9 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
             }
             int amb[NRR] = {0}, cv[NRR] = {0};
             unsigned lvl = 0;
+            unsigned lxn[NRR];                                           // the next level's bounds, requested one level ahead
+#pragma unroll
+            for (int r = 0; r < NR; ++r) lxn[r] = lox_lds[(r * NT) * 64 + lane];
 #pragma unroll
             for (int L = 1; L <= NT; ++L) {
                 static_assert(NT <= 32, "one 32-bit sign collector per level");
@@ -368,7 +371,8 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     below[r] = 0u;
-                    lx[r] = lox_lds[(r * NT + (L - 1)) * 64 + lane];
+                    lx[r] = lxn[r];
+                    if (L < NT) lxn[r] = lox_lds[(r * NT + L) * 64 + lane];
                     umin[r] = 0xFFFFFFFFu;
                 }
                 float tmin = __builtin_inff();
@@ -378,7 +382,7 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
                     const float sum = L == 1 ? de : sums[s] + de;
                     sums[s] = sum;
                     const unsigned sb = __float_as_uint(sum);
-                    if (TOPK) tmin = sum < tmin ? sum : tmin;
+                    if (TOPK) tmin = __builtin_fminf(sum, tmin);
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
                         const unsigned u = sb - lx[r];
@@ -609,17 +613,13 @@ __global__ __launch_bounds__(64) void score_pairs_exact_kernel(const float *__re
         float d[NT];
 #pragma unroll
         for (int c = 0; c < NT; ++c) d[c] = (have && c < n) ? dx[lane * NT + c] : __builtin_inff();
+        // every lane has its own query's keys: the exact score (IEEE division, as the reference path computes it) against the
+        // key distance -- no per-lane table rows to gather
         int cntr[NR] = {0};
-        float sums[NT];
-        const unsigned *tq = m.tab + (qi * NR) * NT * MF_TAB;
+        float sums[NT], xk[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) xk[r] = rank_dist[r * a.Nq + qi];
         bool tie = false;
-        // every lane's bounds come from a different query's table rows: all of them requested at once (one memory round trip
-        // for the batch instead of one per span length)
-        uint2 bnd[NR][NT];
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-#pragma unroll
-            for (int L = 1; L <= NT; ++L) bnd[r][L - 1] = *reinterpret_cast<const uint2 *>(tq + (r * NT + (L - 1)) * MF_TAB);
 #pragma unroll
         for (int L = 1; L <= NT; ++L) {
 #pragma unroll
@@ -627,16 +627,16 @@ __global__ __launch_bounds__(64) void score_pairs_exact_kernel(const float *__re
                 const float de = d[s + L - 1];
                 const float sum = L == 1 ? de : sums[s] + de;
                 sums[s] = sum;
-                const unsigned sb = __float_as_uint(sum);
+                const float sc = sum / (float)L;
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    cntr[r] += sb < bnd[r][L - 1].x ? 1 : 0;
-                    tie = tie || (sb >= bnd[r][L - 1].x && sb < bnd[r][L - 1].y);
+                    cntr[r] += sc < xk[r] ? 1 : 0;
+                    tie = tie || sc == xk[r];
                 }
             }
         }
         if (__ballot(tie && rmask != 0u)) {
-            // score == a rank key somewhere: walk this lane's video once more with the exact division and break ties by id
+            // score == a rank key somewhere: walk this lane's video once more and break the ties by moment id
             if (tie) {
 #pragma nounroll
                 for (int s = 0; s < n; ++s) {
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(64) void score_pairs_exact_kernel(const float *__re
                         const unsigned id = (unsigned)(a.id_base + mbase + moment_index(n, s, e));
 #pragma unroll
                         for (int r = 0; r < NR; ++r)
-                            if (sc == rank_dist[r * a.Nq + qi] && id < (unsigned)rank_idx[r * a.Nq + qi]) cntr[r] += 1;
+                            if (sc == xk[r] && id < (unsigned)rank_idx[r * a.Nq + qi]) cntr[r] += 1;
                     }
                 }
             }
