@@ -719,3 +719,110 @@ def test_gt_labels_kernel_equals_host_table(vfr, clips):
         want = engine.gt_label_table(times, counts[own], thrs, strict=strict)
         got = engine.gt_labels(times, counts[own], thrs, strict, DEV, ops)
         assert got.dtype == torch.bool and got.is_cuda and np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_vgg19_full_size_bit_exact_and_torch_fixture(vfr, oracle, golden):
+    """BASELINE config 3 at full size: 224x224 frames, VGG-19 "E" widths 64..512, fc6 25088 -> 4096, fc7 -- conv1_1's Cin 3 -> 4
+    padding, the 128x64 tiles at 100k-pixel M, fc6 at K = 25088.  HIP == oracle bit for bit on 2 frames; frame 0 == fixture G9
+    (torch.nn modules, generated from the reference's layer list) within 1e-4 of the activation scale."""
+    from test_oracle_vgg_torch import VGG19_E
+    cw, cb, fc6, fc7 = synth.vgg_weights(VGG19_E, (224, 224), 4096, seed=5)
+    frames = np.concatenate([synth.frames_u8(1, 224, 224, seed=5), synth.frames_u8(1, 224, 224, seed=6)])
+    got = vfr.vgg_fc7(dev(frames), VGG19_E, [dev(w) for w in cw], [dev(b) for b in cb],
+                      (dev(fc6[0]), dev(fc6[1])), (dev(fc7[0]), dev(fc7[1])))
+    want = oracle.vgg_fc7(frames, cw, cb, fc6, fc7, VGG19_E)
+    assert same(got, want)
+    ref = golden("g9_vgg_full.npz")["fc7"]
+    np.testing.assert_allclose(got.cpu().numpy()[:1], ref, rtol=0, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
+    # the extractor's chunked pass (160-frame chunks) over a full 150-frame video: every frame independent of its batch
+    rs = np.random.RandomState(3)
+    video = rs.randint(0, 256, size=(150, 224, 224, 3)).astype(np.uint8)
+    video[7], video[149] = frames[0], frames[1]
+    full = vfr.vgg_fc7(dev(video), VGG19_E, [dev(w) for w in cw], [dev(b) for b in cb],
+                       (dev(fc6[0]), dev(fc6[1])), (dev(fc7[0]), dev(fc7[1])))
+    assert torch.equal(full[7], got[0]) and torch.equal(full[149], got[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,clips", [("n6", 6), ("ragged", "didemo"), ("n21", 21)])
+def test_bf16_scoring_tolerance_on_reference_embeddings(vfr, oracle, golden, tag, clips):
+    """BASELINE config 5 (bf16 MFMA operands, fp32 accumulate) on the REFERENCE's own embeddings (fixture G2).  Stated
+    tolerance: rank@1 identical to the fp32 path for >= 98 % of the queries and to the reference's argsort top-1 likewise,
+    top-10 overlap >= 0.95, every returned distance an EXACT fp32 score of its moment (the list is re-ranked exactly), rank
+    counts within 2 % of the number of moments."""
+    g = golden(f"g2_scoring_{tag}.npz")
+    Q, V, counts = g["query_emb"], g["visual_emb"], g["counts"]
+    off = synth.clip_offsets(counts)
+    bank = _bank(vfr, V, off)
+    d0, i0, _ = vfr.score_topk(dev(Q), bank, 100, mode="exact")
+    d1, i1, _ = vfr.score_topk(dev(Q), bank, 100, mode="bf16")
+    i0n, i1n = i0.cpu().numpy(), i1.cpu().numpy()
+    assert (i0n[:, 0] == i1n[:, 0]).mean() >= 0.98
+    assert (i1n[:, 0] == g["top_idx"][:, 0]).mean() >= 0.98
+    assert np.mean([len(set(a[:10]) & set(b[:10])) / 10 for a, b in zip(i0n, i1n)]) >= 0.95
+    dense = oracle.score_moments(Q, V, off)
+    assert np.array_equal(d1.cpu().numpy(), np.take_along_axis(dense, i1n, axis=1))       # exact scores of the listed moments
+    assert bool((d1[:, 1:] >= d1[:, :-1]).all())
+    rs = np.random.RandomState(2)
+    pick = rs.randint(0, dense.shape[1], size=(2, Q.shape[0]))
+    rd = np.take_along_axis(dense, pick.T, axis=1).T.copy()
+    _, _, c0 = vfr.score_topk(dev(Q), bank, 0, dev(rd), dev(pick.astype(np.int64)), mode="exact")
+    _, _, c1 = vfr.score_topk(dev(Q), bank, 0, dev(rd), dev(pick.astype(np.int64)), mode="bf16")
+    assert float((c0 - c1).abs().max()) <= 0.02 * dense.shape[1]
+
+
+@pytest.mark.gpu
+def test_bf16_scoring_tolerance_full_corpus(vfr):
+    """Config 5 at BASELINE size (10k videos x 21 clips, 256-query batch): rank@1 agreement >= 0.99, top-10 overlap >= 0.98,
+    top-100 overlap >= 0.95 against the fp32 path, rank counts within 1 % of the 2.31 M moments."""
+    torch.manual_seed(1)
+    nv, n, nq, k = 10000, 21, 256, 100
+    V = torch.randn(nv * n, 100, device=DEV) * 0.1
+    Q = torch.randn(nq, 100, device=DEV) * 0.1
+    off = torch.arange(0, nv * n + 1, n, dtype=torch.int32, device=DEV)
+    bank = vfr.VideoBank(V, off)
+    d0, i0, _ = vfr.score_topk(Q, bank, k, mode="mfma")
+    rd = torch.stack([d0[:, 40], d0[:, 99] * 1.05]).contiguous()
+    ri = torch.stack([i0[:, 40], i0[:, 99]]).contiguous()
+    d0, i0, c0 = vfr.score_topk(Q, bank, k, rd, ri, mode="mfma")
+    d1, i1, c1 = vfr.score_topk(Q, bank, k, rd, ri, mode="bf16")
+    assert float((i0[:, 0] == i1[:, 0]).float().mean()) >= 0.99
+    assert float((i0[:, :10, None] == i1[:, None, :10]).any(-1).float().mean()) >= 0.98
+    assert float((i0[:, :, None] == i1[:, None, :]).any(-1).float().mean()) >= 0.95
+    assert bool((c0[0] == 40).all())
+    assert float((c0 - c1).abs().max()) <= 0.01 * nv * n * (n + 1) / 2
+
+
+@pytest.mark.gpu
+def test_mfma_prefilter_answers_itself_and_falls_back_on_duplicates(vfr, oracle):
+    """The fp32 MFMA path must not be the exact kernels in disguise: on a generic corpus no query group is handed to the
+    fallback and only a small fraction of the (query, video) pairs is re-scored exactly; on a corpus of duplicated videos
+    (hundreds of exactly equal scores inside any margin) the groups ARE handed over -- and the result is still exact."""
+    rs = np.random.RandomState(5)
+    counts = synth.clip_counts(1500, 21, seed=5)
+    off = synth.clip_offsets(counts)
+    V = (rs.randn(int(off[-1]), 100) * 0.1).astype(np.float32)
+    Q = (rs.randn(200, 100) * 0.1).astype(np.float32)
+    bank = _bank(vfr, V, off)
+    dense = oracle.score_moments(Q[:8], V, off)
+    d, i, _ = vfr.score_topk(dev(Q), bank, 100, mode="exact")
+    rd = torch.stack([d[:, 50], d[:, 99] * 1.1]).contiguous()
+    ri = torch.stack([i[:, 50], i[:, 99]]).contiguous()
+    ws = vfr.topk_workspace(200, 1500, 100, DEV, total_clips=int(off[-1]))
+    d1, i1, c1 = vfr.score_topk(dev(Q), bank, 100, rd, ri, workspace=ws, mode="mfma")
+    st = vfr.score_mfma_stats(ws, 200, bank, 100)
+    assert st["fallback_groups"] == 0 and 0 < st["exact_pair_fraction"] < 0.3, st
+    d0, i0, c0 = vfr.score_topk(dev(Q), bank, 100, rd, ri, mode="exact")
+    assert torch.equal(i0, i1) and torch.equal(d0, d1) and torch.equal(c0, c1)
+    order = np.argsort(dense, axis=1, kind="stable")[:, :100]
+    assert np.array_equal(i1.cpu().numpy()[:8], order)
+    # duplicated videos: 300 copies of one video -> every best moment 300 times
+    Vd = np.tile(V[:21], (300, 1))
+    offd = synth.clip_offsets(np.full(300, 21))
+    bankd = _bank(vfr, Vd, offd)
+    wsd = vfr.topk_workspace(200, 300, 100, DEV, total_clips=int(offd[-1]))
+    dd, idd, _ = vfr.score_topk(dev(Q), bankd, 100, workspace=wsd, mode="mfma")
+    assert vfr.score_mfma_stats(wsd, 200, bankd, 100)["fallback_groups"] > 0
+    wd, wi = oracle.score_topk(Q, Vd, offd, 100)
+    assert same(idd, wi) and same(dd, wd)

@@ -37,3 +37,17 @@ def test_oracle_vgg_matches_torch_functional(oracle, hw):
     want = F.relu(F.linear(x, torch.from_numpy(fc7[0]), torch.from_numpy(fc7[1]))).numpy()
     scale = max(1.0, float(np.abs(want).max()))
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * scale)
+
+
+VGG19_E = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+
+
+def test_oracle_vgg_full_size_frame_matches_torch_modules(oracle, golden):
+    """BASELINE config 3 at FULL size: one 224x224 frame, true VGG-19 "E" widths, fc6 25088 -> 4096 -> fc7, against fixture G9
+    (the same stack built from torch.nn.Conv2d / MaxPool2d / AdaptiveAvgPool2d / Linear modules by tools/gen_golden.py).
+    Still 'unpinned vs torchvision' (absent here, weights a network fetch): this pins the composition and the arithmetic."""
+    want = golden("g9_vgg_full.npz")["fc7"]
+    cw, cb, fc6, fc7 = synth.vgg_weights(VGG19_E, (224, 224), 4096, seed=5)
+    got = oracle.vgg_fc7(synth.frames_u8(1, 224, 224, seed=5), cw, cb, fc6, fc7, VGG19_E)
+    assert got.shape == want.shape == (1, 4096)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want).max())))
