@@ -28,10 +28,12 @@ def vfr():
 def score_mode(request, vfr):
     """Every scoring test runs twice: the exact VALU kernels, and the fp32 MFMA pre-filter + exact re-scoring path
     (vfr_score_topk_mfma, dtype f32), whose outputs must be the same bits."""
-    old = vfr.DEFAULT_SCORE_MODE
+    old, old_min = vfr.DEFAULT_SCORE_MODE, vfr.get_option("score_mfma_min")
     vfr.DEFAULT_SCORE_MODE = request.param
+    vfr.set_option("score_mfma_min", 0)              # the tests' small banks must reach the pre-filter kernels too
     yield request.param
     vfr.DEFAULT_SCORE_MODE = old
+    vfr.set_option("score_mfma_min", old_min)
 
 
 def dev(a, dtype=None):
@@ -818,6 +820,7 @@ def test_mfma_prefilter_answers_itself_and_falls_back_on_duplicates(vfr, oracle)
     order = np.argsort(dense, axis=1, kind="stable")[:, :100]
     assert np.array_equal(i1.cpu().numpy()[:8], order)
     # duplicated videos: 300 copies of one video -> every best moment 300 times
+    vfr.set_option("score_mfma_min", 0)
     Vd = np.tile(V[:21], (300, 1))
     offd = synth.clip_offsets(np.full(300, 21))
     bankd = _bank(vfr, Vd, offd)
@@ -825,4 +828,5 @@ def test_mfma_prefilter_answers_itself_and_falls_back_on_duplicates(vfr, oracle)
     dd, idd, _ = vfr.score_topk(dev(Q), bankd, 100, workspace=wsd, mode="mfma")
     assert vfr.score_mfma_stats(wsd, 200, bankd, 100)["fallback_groups"] > 0
     wd, wi = oracle.score_topk(Q, Vd, offd, 100)
+    vfr.set_option("score_mfma_min", 128)
     assert same(idd, wi) and same(dd, wd)

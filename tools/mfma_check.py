@@ -15,6 +15,7 @@ import vfr_amd  # noqa: E402,F401
 from vfr_amd import _vfr  # noqa: E402
 
 dev = torch.device("cuda", 0)
+_vfr.set_option("score_mfma_min", 0)                  # small cases must exercise the pre-filter kernels
 
 
 def run(nv, nq, clips, k, scale=0.1, seed=0, reps=3):

@@ -1167,6 +1167,12 @@ static bool mfma_applicable(int D, int max_clips, int num_rank, int k, int Nv, i
     return D == FAST_D && max_clips <= 21 && (num_rank == 0 || num_rank == 2) && (k > 0 || num_rank > 0) && Nv > 0 &&
            total_clips > 0 && (k == 0 || k + MF_EXTRA + M <= 512);
 }
+// banks this small (a multi-GPU threshold sample, a handful of videos) cost less on the exact kernels than the pre-filter's
+// fixed launches (pre-passes, finisher, masked fallback ladder)
+static bool mfma_worthwhile(int Nv, int dtype)
+{
+    return dtype == VFR_MFMA_BF16 || Nv >= opt_mfma_min();
+}
 
 template <int MODE>
 static int launch_score(const ScoreArgs &a, int kpl, hipStream_t st, int *cap_transposed = nullptr)
@@ -1457,7 +1463,7 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
                 "vfr_score_topk_mfma: workspace %zu < %zu bytes", workspace_bytes,
                 vfr_score_topk_mfma_workspace_bytes(Nq, Nv, total_clips, k));
     if (!(Q && V && clip_offsets && moment_offsets && Nq > 0 && k >= 0 && num_rank >= 0) ||
-        !vfr::mfma_applicable(D, max_clips, num_rank, k, Nv, total_clips) || !vfr::opt_score_fast()) {
+        !vfr::mfma_applicable(D, max_clips, num_rank, k, Nv, total_clips) || !vfr::mfma_worthwhile(Nv, dtype) || !vfr::opt_score_fast()) {
         // shapes the pre-filter is not built for: the exact kernels give the same results in f32 mode
         VFR_REQUIRE(dtype == VFR_MFMA_F32, VFR_EUNSUPPORTED,
                     "vfr_score_topk_mfma(bf16): needs D = 100, <= 21 clips per video, 0 or 2 rank keys, k <= %d", 512 - 231 - vfr::MF_EXTRA);
@@ -1482,12 +1488,15 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
         vfr::ProfScope prof(vfr::SITE_SCORE_PREP, st);
         hipLaunchKernelGGL(vfr::mfma_prep_v_kernel, dim3((unsigned)vfr::cdiv(total_clips, 4)), dim3(256), 0, st, V, total_clips, D, eps,
                            mw.va, mw.rv, bf16 ? mw.vb : nullptr);
-        if (NT == 6)
-            hipLaunchKernelGGL((vfr::mfma_prep_q_kernel<6>), dim3((unsigned)vfr::cdiv(Nq, 64)), dim3(64), 0, st, Q, Nq, D, eps, mw.rv, num_rank,
-                               rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0);
-        else
-            hipLaunchKernelGGL((vfr::mfma_prep_q_kernel<21>), dim3((unsigned)vfr::cdiv(Nq, 64)), dim3(64), 0, st, Q, Nq, D, eps, mw.rv, num_rank,
-                               rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0);
+        hipLaunchKernelGGL(vfr::mfma_prep_q_kernel, dim3((unsigned)vfr::cdiv(Nq, 64)), dim3(64), 0, st, Q, Nq, D, eps, mw.rv, num_rank, rank_dist,
+                           mw.qmeta);
+        if (num_rank > 0) {
+            const dim3 tg((unsigned)vfr::cdiv(Nq * num_rank * NT, 256));
+            if (NT == 6)
+                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<6>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0);
+            else
+                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<21>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0);
+        }
         if (k > 0) {
             if (thr_seed)
                 hipLaunchKernelGGL(vfr::mfma_seed_kernel, dim3((unsigned)vfr::cdiv(Nq, 256)), dim3(256), 0, st, thr_seed, mw.qmeta, Nq, w.thr);

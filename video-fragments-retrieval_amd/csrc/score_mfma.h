@@ -88,12 +88,10 @@ __global__ __launch_bounds__(256) void mfma_prep_v_kernel(const float *__restric
         }
 }
 
-// one thread per query: b_q, |q|, E2, the distance floor; then the threshold table rows of its rank keys
-template <int NT>
+// one thread per query: b_q, |q|, E2, the distance floor
 __global__ __launch_bounds__(64) void mfma_prep_q_kernel(const float *__restrict__ Q, int64_t Nq, int D, float eps,
                                                          const float *__restrict__ rv, int NR,
-                                                         const float *__restrict__ rank_dist, float4 *__restrict__ qmeta,
-                                                         unsigned *__restrict__ tab, int bf16_mode)
+                                                         const float *__restrict__ rank_dist, float4 *__restrict__ qmeta)
 {
     const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (q >= Nq) return;
@@ -111,30 +109,40 @@ __global__ __launch_bounds__(64) void mfma_prep_q_kernel(const float *__restrict
     for (int r = 0; r < NR; ++r) { const float x = rank_dist[r * Nq + q]; xmin = x < xmin ? x : xmin; }
     const float dfl = NR > 0 && xmin < __builtin_inff() ? 0.75f * xmin : 0.0f;
     qmeta[q] = make_float4(bq, dfl, E2, qn);
-    for (int r = 0; r < NR; ++r) {
-        const float x = rank_dist[r * Nq + q];
-        for (int L = 1; L <= NT; ++L) {
-            unsigned *t = tab + ((q * NR + r) * NT + (L - 1)) * MF_TAB;
-            const float lo = sum_bound<true>(x, L), hi = sum_bound<false>(x, L);
-            const unsigned LOX = min(excl_bound(lo), 0x7F800000u), HIX = min(excl_bound(hi), 0x7F800000u);
-            unsigned LOW = LOX, HIW = HIX;
-            if (!bf16_mode && x < __builtin_inff()) {
-                // Delta_L: see the header.  S is at most hi + Delta_L near the window; (56 + 2L) u S with 2 % head-room.
-                const float Sref = (hi > 0.0f ? hi : 0.0f) + (float)L * 1e-3f;
-                const float delta = dfl > 0.0f ? ((float)L * E2 / dfl + (float)(56 + 2 * L) * MF_U * Sref * 1.02f) * 1.0001f
-                                               : __builtin_inff();
-                float low = lo - delta;                                   // lo = -1: no sum is below the key
-                low = low > 0.0f ? next_down(low) : -1.0f;
-                float hiw = (hi > 0.0f ? hi : 0.0f) + delta;
-                hiw = hiw < __builtin_inff() ? next_up(hiw) : hiw;
-                LOW = min(excl_bound(low), 0x7F800000u);
-                HIW = min(excl_bound(hiw), 0x7F800000u);
-                if (HIW < HIX) HIW = HIX;
-                if (LOW > LOX) LOW = LOX;
-            }
-            t[0] = LOX; t[1] = HIX; t[2] = LOW; t[3] = HIW - LOW;
-        }
+}
+
+// one thread per (query, rank key, span length): the exact bit bounds of the sum and their widened forms
+template <int NT>
+__global__ __launch_bounds__(256) void mfma_prep_tab_kernel(int64_t Nq, int NR, const float *__restrict__ rank_dist,
+                                                            const float4 *__restrict__ qmeta, unsigned *__restrict__ tab,
+                                                            int bf16_mode)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Nq * NR * NT) return;
+    const int L = (int)(i % NT) + 1, r = (int)((i / NT) % NR);
+    const int64_t q = i / ((int64_t)NT * NR);
+    const float4 meta = qmeta[q];
+    const float dfl = meta.y, E2 = meta.z;
+    const float x = rank_dist[r * Nq + q];
+    unsigned *t = tab + i * MF_TAB;
+    const float lo = sum_bound<true>(x, L), hi = sum_bound<false>(x, L);
+    const unsigned LOX = min(excl_bound(lo), 0x7F800000u), HIX = min(excl_bound(hi), 0x7F800000u);
+    unsigned LOW = LOX, HIW = HIX;
+    if (!bf16_mode && x < __builtin_inff()) {
+        // Delta_L: see the header.  S is at most hi + Delta_L near the window; (56 + 2L) u S with 2 % head-room.
+        const float Sref = (hi > 0.0f ? hi : 0.0f) + (float)L * 1e-3f;
+        const float delta = dfl > 0.0f ? ((float)L * E2 / dfl + (float)(56 + 2 * L) * MF_U * Sref * 1.02f) * 1.0001f
+                                       : __builtin_inff();
+        float low = lo - delta;                                           // lo = -1: no sum is below the key
+        low = low > 0.0f ? next_down(low) : -1.0f;
+        float hiw = (hi > 0.0f ? hi : 0.0f) + delta;
+        hiw = hiw < __builtin_inff() ? next_up(hiw) : hiw;
+        LOW = min(excl_bound(low), 0x7F800000u);
+        HIW = min(excl_bound(hiw), 0x7F800000u);
+        if (HIW < HIX) HIW = HIX;
+        if (LOW > LOX) LOW = LOX;
     }
+    *reinterpret_cast<uint4 *>(t) = make_uint4(LOX, HIX, LOW, HIW - LOW);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -679,6 +687,13 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const unsigned long lo
     const int64_t q = (int64_t)blockIdx.x * 4 + wv;
     if (q >= Nq) return;
     const float *qr = Q + q * D;
+    __shared__ __attribute__((aligned(16))) float qs_all[4][FAST_D];
+    float *qs = qs_all[wv];
+    if (D == FAST_D) {
+        for (int kk = lane; kk < FAST_D; kk += 64) qs[kk] = qr[kk];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
     unsigned long long key[KPL];
 #pragma unroll
     for (int i = 0; i < KPL; ++i) {
@@ -712,9 +727,21 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const unsigned long lo
         for (int c = s; c <= e2; ++c) {
             const float *vr = V + (int64_t)(c0 + c) * D;
             float acc = 0.0f;
-            for (int kk = 0; kk < D; ++kk) {
-                const float dd = (vr[kk] - qr[kk]) + eps;
-                acc = __builtin_fmaf(dd, dd, acc);
+            if (D == FAST_D) {                                            // 16-byte loads, five in flight; q from the wave's LDS copy
+                const float4 *v4 = reinterpret_cast<const float4 *>(vr), *q4 = reinterpret_cast<const float4 *>(qs);
+#pragma unroll 5
+                for (int j4 = 0; j4 < FAST_D / 4; ++j4) {
+                    const float4 x = v4[j4], y = q4[j4];
+                    float dd = (x.x - y.x) + eps; acc = __builtin_fmaf(dd, dd, acc);
+                    dd = (x.y - y.y) + eps; acc = __builtin_fmaf(dd, dd, acc);
+                    dd = (x.z - y.z) + eps; acc = __builtin_fmaf(dd, dd, acc);
+                    dd = (x.w - y.w) + eps; acc = __builtin_fmaf(dd, dd, acc);
+                }
+            } else {
+                for (int kk = 0; kk < D; ++kk) {
+                    const float dd = (vr[kk] - qr[kk]) + eps;
+                    acc = __builtin_fmaf(dd, dd, acc);
+                }
             }
             const float dc = __builtin_sqrtf(acc);
             sum = c == s ? dc : sum + dc;

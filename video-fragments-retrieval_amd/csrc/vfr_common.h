@@ -26,6 +26,7 @@ int opt_lstm_xcd();
 int opt_gemm_small();
 int opt_lstm_tile();
 int opt_gemm_pp();
+int opt_mfma_min();
 
 // ---- launch-site profiler (vfr_set_option("profile", 1)): HIP events recorded on the launch stream
 // around every instrumented launch; vfr_profile_read() turns them into per-site totals after a sync.
