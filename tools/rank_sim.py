@@ -16,6 +16,8 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 OVERLAP = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 if len(sys.argv) > 4:
     _vfr.set_option("lstm_tile", int(sys.argv[4]))
+for _item in filter(None, __import__("os").environ.get("VFR_OPTS", "").split(",")):     # e.g. VFR_OPTS=score_tasks=4096
+    _vfr.set_option(_item.split("=")[0], int(_item.split("=")[1]))
 Nv_all, Nq, n, F, k = 10000, 5000, 21, 4096, 100
 dev = torch.device("cuda:0")
 
@@ -27,6 +29,12 @@ class FakeDist:
 
     def all_gather(self, parts, t):
         FakeDist.calls += 1
+        if t.dim() == 1 and t.numel() == Nq * k + 2 * Nq:
+            # first exchange of sharded_search_fused: [sample keys | best-GT keys]; queries owned by other ranks get a typical key
+            gtk = t[Nq * k:]
+            inf = gtk == engine.KEY_INF
+            if bool(inf.any()):
+                gtk[inf] = gtk[~inf].median()
         for p in parts:
             p.copy_(t)
 

@@ -364,16 +364,17 @@ def prepare_gt(shard: CorpusShard, own_global, labels, index: QueryGT | None = N
     return gt
 
 
-def best_positive_keys(shard: CorpusShard, Q, gt: QueryGT, ops, world=1):
+def best_positive_keys(shard: CorpusShard, Q, gt: QueryGT, ops, world=1, reduce=True):
     """Per (threshold, query): key of the best ground-truth-positive moment = min over positives of
-    (score, global id).  Only the rank that owns the query's video can see it; others contribute KEY_INF."""
+    (score, global id).  Only the rank that owns the query's video can see it; others contribute KEY_INF.
+    ``reduce=False`` returns this rank's keys only (the caller folds the MIN into another exchange)."""
     if gt.sel is not None:
         sc = ops.score_own(Q[gt.sel].contiguous(), shard.bank, gt.own_local)      # [n_sel, Mown], +inf padded
         keys = ops.gt_best_keys(sc, gt.labels, gt.base, gt.sel, gt.num_queries)
     else:
         keys = torch.full((gt.num_thresholds, gt.num_queries), KEY_INF, dtype=torch.int64, device=shard.device)
     dist = _dist() if world > 1 else None
-    if dist is not None:
+    if dist is not None and reduce:
         dist.all_reduce(keys, op=dist.ReduceOp.MIN)
     return keys
 
@@ -386,26 +387,38 @@ def corpus_ranks(shard: CorpusShard, Q, own_global, labels, ops=None, k=0, world
     in the reference (Q3)."""
     ops = ops or HipOps()
     gt = gt if gt is not None else prepare_gt(shard, own_global, labels)
-    keys = best_positive_keys(shard, Q, gt, ops, world)
-    # "no positive moment" is known as soon as the keys are: its flag travels to pinned host memory right behind them and is
-    # read AFTER the passes below are queued, waiting only for that copy -- the host is never held until the scoring ends, so
-    # it can already queue the next batch's encoders
-    missing = (keys == KEY_INF).any()
-    async_check = keys.is_cuda
-    if async_check:
-        flags = _TLS.__dict__.setdefault("flags", {})
-        flag = flags.get(keys.device)
-        if flag is None:
-            flag = flags[keys.device] = torch.empty((), dtype=torch.bool).pin_memory()
-        flag.copy_(missing, non_blocking=True)
-        landed = torch.cuda.Event()
-        landed.record()
+    fused = world > 1 and k > 0 and gt.num_thresholds == 2 and _dist() is not None
+    keys = best_positive_keys(shard, Q, gt, ops, world, reduce=not fused)
+    state = {}
+
+    def watch(keys_global):
+        # "no positive moment" is known as soon as the (global) keys are: its flag travels to pinned host memory right behind
+        # them and is read AFTER the passes below are queued, waiting only for that copy -- the host is never held until the
+        # scoring ends, so it can already queue the next batch's encoders
+        state["missing"] = (keys_global == KEY_INF).any()
+        state["async"] = keys_global.is_cuda
+        if state["async"]:
+            flags = _TLS.__dict__.setdefault("flags", {})
+            flag = flags.get(keys_global.device)
+            if flag is None:
+                flag = flags[keys_global.device] = torch.empty((), dtype=torch.bool).pin_memory()
+            flag.copy_(state["missing"], non_blocking=True)
+            state["flag"] = flag
+            state["landed"] = torch.cuda.Event()
+            state["landed"].record()
 
     def check():
-        if async_check:
-            landed.synchronize()
-        if bool(flag if async_check else missing):
+        if state["async"]:
+            state["landed"].synchronize()
+        if bool(state["flag"] if state["async"] else state["missing"]):
             raise IndexError("index 0 is out of bounds for axis 0 with size 0 (no ground-truth-positive moment)")
+    if fused:
+        # three collectives per pass instead of five: the best-GT keys ride on the sample exchange, the rank counts on the
+        # final one (sharded_search_fused)
+        od, oi, counts = sharded_search_fused(shard, Q, k, keys, ops, world, workspace, watch)
+        check()
+        return counts, od, oi
+    watch(keys)
     rank_dist, rank_idx = _unpack_key(keys)
     R = keys.shape[0]
     if R == 2:
@@ -472,6 +485,54 @@ def sharded_search(shard: CorpusShard, Q, k, rank_dist, rank_idx, ops, world=1, 
     _all_gather_rows(dist, buf[:world], mine)
     od, oi, _ = ops.merge_keys(buf)
     return od, oi, cnt
+
+
+def sharded_search_fused(shard: CorpusShard, Q, k, keys_local, ops, world, workspace=None, on_keys=None):
+    """``sharded_search`` with the small reductions folded into its two list exchanges (k > 0, two rank keys):
+
+        exchange 1  all_gather of [Nq x k sample keys | 2 x Nq best-GT keys] per rank -> the global sample top-k (its k-th key
+                    seeds every rank's main pass) and, by a MIN over the ranks, the global best-GT keys;
+        exchange 2  all_gather of [Nq x k final keys | 2 x Nq rank counts] per rank -> the merged top-k and, by a SUM over the
+                    ranks, the global rank counts.
+
+    The sample pass therefore runs without rank keys; the sample videos get a rank-only pass (k = 0) once the global keys
+    are known.  Everything stays int64 (keys and counts), so both folds are exact.  Returns (dist, idx, counts)."""
+    dist = _dist()
+    Nq = Q.shape[0]
+    nloc = shard.hi - shard.lo
+    counts_loc = shard.counts_all[shard.lo:shard.hi]
+    s_r = min(nloc, max(1, -(-SAMPLE_VIDEOS // world)))
+    bank_a = ops.slice_bank(shard.bank, counts_loc, 0, s_r)
+    d_a, i_a, _ = ops.score_topk(Q, bank_a, k, None, None, workspace=workspace)
+    row = Nq * k + 2 * Nq
+    mine = torch.empty((row,), dtype=torch.int64, device=d_a.device)
+    ops.pack_keys(d_a, i_a, out=mine[:Nq * k].view(Nq, k))
+    mine[Nq * k:].copy_(keys_local.reshape(-1))
+    buf = torch.empty((world, row), dtype=torch.int64, device=d_a.device)
+    _all_gather_rows(dist, buf, mine)
+    keys = buf[:, Nq * k:].min(dim=0).values.view(2, Nq)                             # global best-GT keys (KEY_INF: none)
+    if on_keys is not None:
+        on_keys(keys)
+    lists = torch.empty((world + 1, Nq, k), dtype=torch.int64, device=d_a.device)    # slot `world`: the global sample list
+    lists[:world].copy_(buf[:, :Nq * k].view(world, Nq, k))
+    _, _, s_k = ops.merge_keys(lists[:world], want_lists=False, want_keys=True)
+    lists[world].copy_(s_k)
+    seed = s_k[:, k - 1].contiguous()
+    rank_dist, rank_idx = _unpack_key(keys)
+    rank_dist, rank_idx = rank_dist.contiguous(), rank_idx.contiguous()
+    _, _, cnt = ops.score_topk(Q, bank_a, 0, rank_dist, rank_idx, workspace=workspace)         # the sample videos' counts
+    if s_r < nloc:
+        bank_b = ops.slice_bank(shard.bank, counts_loc, s_r, nloc)
+        d_b, i_b, cnt = ops.score_topk(Q, bank_b, k, rank_dist, rank_idx, workspace=workspace, count_lt=cnt, thr_seed=seed)
+        ops.pack_keys(d_b, i_b, out=mine[:Nq * k].view(Nq, k))
+    else:
+        mine[:Nq * k].fill_(KEY_INF)
+    mine[Nq * k:].copy_(cnt.reshape(-1))
+    _all_gather_rows(dist, buf, mine)
+    counts = buf[:, Nq * k:].sum(dim=0).view(2, Nq)
+    lists[:world].copy_(buf[:, :Nq * k].view(world, Nq, k))
+    od, oi, _ = ops.merge_keys(lists)
+    return od, oi, counts
 
 
 def gather_merge_topk(od, oi, ops, world, extra=None):
