@@ -210,6 +210,23 @@ int vfr_ranking_loss_grad_f32(const float *posit, const float *intra, const floa
                               float eps, const float *grad_loss, const void *workspace, float *grad_posit, float *grad_intra,
                               float *grad_inter, float *grad_lang, vfr_stream_t stream);
 
+/* ---- f2 (second half)  the encoders' backward: loss.backward() through CALModel.forward, model/main.py:58-67 with
+ * model/models.py:21-26 (visual_fc) and :40-47,61-66 (lstm, lang_fc).  The gradient contractions are vfr_linear_f32 on
+ * transposed operands (dX = dY W, dW = dY^T X); these are the pieces around them (train.py wires them into autograd):
+ *   transpose      out [cols, rows] = in [rows, cols]^T
+ *   colsum         out[c] = sum_r in[r][c], rows in ascending order (bias gradients; deterministic)
+ *   relu_backward  out = act > 0 ? grad : 0
+ *   lstm_cell_forward   one step of nn.LSTM's cell (gates i, f, g, o): pre [B,4H] = h_prev W_hh^T + b_hh, the input part
+ *                  x_t W_ih^T + b_ih of batch row b at xproj + b * x_stride; writes the ACTIVATED gates [B,4H], c, h [B,H]
+ *   lstm_cell_backward  one step of BPTT: (dh [B,H], dc [B,H] in/out) + the step's gates and cell states -> dpre [B,4H]   */
+int vfr_transpose_f32(const float *in, int64_t rows, int64_t cols, float *out, vfr_stream_t stream);
+int vfr_colsum_f32(const float *in, int64_t rows, int cols, float *out, vfr_stream_t stream);
+int vfr_relu_backward_f32(const float *grad, const float *act, int64_t n, float *out, vfr_stream_t stream);
+int vfr_lstm_cell_forward_f32(const float *pre, const float *xproj, int64_t x_stride, const float *c_prev, int64_t B, int H,
+                              float *gates, float *c, float *h, vfr_stream_t stream);
+int vfr_lstm_cell_backward_f32(const float *dh, float *dc, const float *gates, const float *c_prev, const float *c_cur, int64_t B,
+                               int H, float *dpre, vfr_stream_t stream);
+
 /* ---- parity probe: elementwise canonical math (0 exp, 1 sigmoid, 2 tanh, 3 x/y, 4 sqrt,
  * 5 fma(x,y,x)) so tests can pin the device's transcendental forms against the oracle's.        */
 int vfr_math_f32(int op, const float *x, const float *y, float *out, int64_t n, vfr_stream_t stream);

@@ -830,3 +830,42 @@ def test_mfma_prefilter_answers_itself_and_falls_back_on_duplicates(vfr, oracle)
     wd, wi = oracle.score_topk(Q, Vd, offd, 100)
     vfr.set_option("score_mfma_min", 128)
     assert same(idd, wi) and same(dd, wd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["plain", "normlang"])
+def test_encoder_backward_hip_matches_reference_gradients(vfr, golden, tag):
+    """f2 second half: training-mode forward + backward of the clip MLP and the BiLSTM in HIP (train.py, csrc/train.hip)
+    against the REFERENCE's gradients (fixture G10: loss.backward() through model/models.py's CALModel), 1e-4 of the scale."""
+    from test_host_logic import _encoder_grad_case
+    from vfr_amd import models as vmodels
+    assert vmodels.HIP_TRAINING
+    _encoder_grad_case(tag, DEV, golden)
+
+
+@pytest.mark.gpu
+def test_encoder_backward_hip_full_size_vs_torch_autograd(vfr):
+    """The same at the real sizes (F = 4096, hidden 1000, 24 clips rows x 3, 40 queries), HIP autograd functions vs
+    torch.nn's autograd on the same device and weights: forward 1e-4, gradients 2e-4 of their scale."""
+    from vfr_amd import models as vmodels
+    sd = synth.model_weights(4096, seed=8)
+    rs = np.random.RandomState(9)
+    x = dev(rs.rand(72, 8194).astype(np.float32))
+    tok = dev(synth.query_tokens(40, seed=9))
+    wv, wl = dev(rs.randn(72, 100).astype(np.float32)), dev(rs.randn(40, 100).astype(np.float32))
+    res = {}
+    for hip in (True, False):
+        vmodels.HIP_TRAINING = hip
+        try:
+            m = make_model(sd).to(DEV).train()
+            m.visual_fc[3].p = 0.0
+            vis, lang = m(x), m(tok, False, DEV)
+            ((vis * wv).sum() + (lang * wl).sum()).backward()
+            res[hip] = (vis.detach(), lang.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        finally:
+            vmodels.HIP_TRAINING = True
+    assert torch.allclose(res[True][0], res[False][0], rtol=0, atol=1e-4) and torch.allclose(res[True][1], res[False][1], rtol=0, atol=1e-4)
+    assert set(res[True][2]) == set(res[False][2]) and len(res[True][2]) == 14
+    for name, want in res[False][2].items():
+        scale = max(1.0, float(want.abs().max()))
+        assert float((res[True][2][name] - want).abs().max()) <= 2e-4 * scale, name

@@ -296,3 +296,38 @@ def test_evaluate_chance_baseline_matches_reference(tag, clips, capsys):
     np.random.seed(123)
     vevaluate.evaluate(model, vi, li, ds.annotations, "cpu", model_types=["model", "chance"], preliminary=129)
     assert capsys.readouterr().out.count("chance, IoU=0.5") == 1                     # len == m * preliminary + 1 still prints
+
+
+def _encoder_grad_case(tag, device, golden):
+    """The reference's loss.backward() case of fixture G10 through OUR CALModel on `device`."""
+    from vfr_amd import models as vmodels, synth
+    g = golden("g10_encoder_grads.npz")
+    nl = tag == "normlang"
+    sd = synth.model_weights(16, vocab=60, hidden=24, seed=31, normalize_lang=nl)
+    m = vmodels.CALModel(2 * 16 + 2, pretrained_emb=torch.from_numpy(sd["word_embedding.weight"]), hidden_size=24,
+                         dropout_rate=0.0, normalize_lang=nl)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(device).train()
+    rs = np.random.RandomState(32)
+    x = torch.from_numpy(rs.rand(37, 34).astype(np.float32)).to(device)
+    tok = torch.from_numpy(synth.query_tokens(11, vocab=60, seed=33)).to(device)
+    wv = torch.from_numpy(rs.randn(37, 100).astype(np.float32)).to(device)
+    wl = torch.from_numpy(rs.randn(11, 100).astype(np.float32)).to(device)
+    vis = m(x)
+    lang = m(tok, False, device)
+    ((vis * wv).sum() + (lang * wl).sum()).backward()
+    np.testing.assert_allclose(vis.detach().cpu().numpy(), g[f"{tag}_vis"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(lang.detach().cpu().numpy(), g[f"{tag}_lang"], rtol=0, atol=1e-4)
+    names = [k[len(tag) + 6:] for k in g.files if k.startswith(f"{tag}_grad_")]
+    assert len(names) >= 14
+    params = dict(m.named_parameters())
+    for name in names:
+        want = g[f"{tag}_grad_{name}"]
+        got = params[name].grad.detach().cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want).max())), err_msg=name)
+
+
+@pytest.mark.parametrize("tag", ["plain", "normlang"])
+def test_encoder_gradients_cpu_device_match_reference(golden, tag):
+    """f2 second half, CPU device: loss.backward() through CALModel (torch.nn path) == the reference's gradients (G10)."""
+    _encoder_grad_case(tag, "cpu", golden)

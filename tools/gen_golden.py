@@ -10,7 +10,8 @@ OUTPUTS plus the recipe parameters; tests regenerate the inputs from the same se
 
 Fixtures:  G1 encoders, G2 scoring + both evaluate() dicts (n=6, n=21, ragged 5/6),
 G3 generate_moments / get_iou, G4 load_video_features pooling, G5 tokeniser + WordIndexer, G6 validate_epoch,
-G7 ranking loss, G8 evaluate() with the 'chance' baseline, G9 one full-size VGG-19 frame through torch.nn modules.
+G7 ranking loss, G8 evaluate() with the 'chance' baseline, G9 one full-size VGG-19 frame through torch.nn modules,
+G10 encoder gradients (loss.backward() through CALModel).
 """
 import json
 import random
@@ -356,6 +357,35 @@ def g9_vgg_full():
     print("G9", out.shape, float(out.max()), float(out.mean()))
 
 
+def g10_encoder_grads():
+    """loss.backward() through the reference's CALModel (model/main.py:58-67 with model/models.py:54-66): gradients of every
+    trainable parameter for a seeded reduced model (F = 16, hidden 24, vocab 60; dropout 0 so the fixture does not depend on
+    torch's RNG), loss = sum(vis * wv) + sum(lang * wl) with fixed weights wv / wl; plain and normalize_lang."""
+    out = {}
+    for tag, nl in (("plain", False), ("normlang", True)):
+        sd = synth.model_weights(16, vocab=60, hidden=24, seed=31, normalize_lang=nl)
+        emb = torch.from_numpy(sd["word_embedding.weight"])
+        m = ref_models.CALModel(2 * 16 + 2, pretrained_emb=emb, hidden_size=24, dropout_rate=0.0, normalize_lang=nl)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        m.train()
+        rs = np.random.RandomState(32)
+        x = torch.from_numpy(rs.rand(37, 34).astype(np.float32))
+        tok = torch.from_numpy(synth.query_tokens(11, vocab=60, seed=33))
+        wv = torch.from_numpy(rs.randn(37, 100).astype(np.float32))
+        wl = torch.from_numpy(rs.randn(11, 100).astype(np.float32))
+        vis = m(x)
+        lang = m(tok, False, "cpu")
+        loss = (vis * wv).sum() + (lang * wl).sum()
+        loss.backward()
+        out[f"{tag}_vis"] = vis.detach().numpy()
+        out[f"{tag}_lang"] = lang.detach().numpy()
+        for name, p_ in m.named_parameters():
+            if p_.grad is not None:
+                out[f"{tag}_grad_{name}"] = p_.grad.numpy().copy()
+    np.savez_compressed(OUT / "g10_encoder_grads.npz", **out)
+    print("G10", sorted(k for k in out if "grad" in k))
+
+
 if __name__ == "__main__":
     g3_moments_iou()
     g5_tokens()
@@ -368,3 +398,4 @@ if __name__ == "__main__":
     g7_ranking_loss()
     g8_chance()
     g9_vgg_full()
+    g10_encoder_grads()

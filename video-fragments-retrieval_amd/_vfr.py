@@ -55,6 +55,11 @@ SIGNATURES = {
     "vfr_ranking_loss_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _sz, _vp]),
     "vfr_ranking_loss_grad_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _vp]),
+    "vfr_transpose_f32": (_i32, [_vp, _i64, _i64, _vp, _vp]),
+    "vfr_colsum_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "vfr_relu_backward_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "vfr_lstm_cell_forward_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "vfr_lstm_cell_backward_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "vfr_frames_normalize_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "vfr_conv3x3_relu_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "vfr_maxpool2_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -463,6 +468,41 @@ def vgg_fc7(frames_thwc, cfg, conv_w, conv_b, fc6, fc7) -> torch.Tensor:
                                  f6b.data_ptr(), f7w.data_ptr(), f7b.data_ptr(), fc_dim, out.data_ptr(), ws.data_ptr(),
                                  nbytes, _stream()), "vfr_vgg_fc7_f32")
     return out
+
+
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    x = _dev(x, torch.float32, "x")
+    r, c = x.shape
+    out = torch.empty((c, r), dtype=torch.float32, device=x.device)
+    _check(lib().vfr_transpose_f32(x.data_ptr(), r, c, out.data_ptr(), _stream()), "vfr_transpose_f32")
+    return out
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    x = _dev(x, torch.float32, "x")
+    out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+    _check(lib().vfr_colsum_f32(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream()), "vfr_colsum_f32")
+    return out
+
+
+def relu_backward(grad: torch.Tensor, act: torch.Tensor) -> torch.Tensor:
+    grad, act = _dev(grad, torch.float32, "grad"), _dev(act, torch.float32, "act")
+    out = torch.empty_like(grad)
+    _check(lib().vfr_relu_backward_f32(grad.data_ptr(), act.data_ptr(), grad.numel(), out.data_ptr(), _stream()), "vfr_relu_backward_f32")
+    return out
+
+
+def lstm_cell_forward(pre, xproj_t, x_stride, c_prev, gates_out, c_out, h_out):
+    """pre [B,4H]; xproj_t = view whose row b starts b * x_stride floats after its first element."""
+    B, H = c_prev.shape
+    _check(lib().vfr_lstm_cell_forward_f32(pre.data_ptr(), xproj_t.data_ptr(), x_stride, c_prev.data_ptr(), B, H, gates_out.data_ptr(),
+                                           c_out.data_ptr(), h_out.data_ptr(), _stream()), "vfr_lstm_cell_forward_f32")
+
+
+def lstm_cell_backward(dh, dc, gates, c_prev, c_cur, dpre_out):
+    B, H = c_prev.shape
+    _check(lib().vfr_lstm_cell_backward_f32(dh.data_ptr(), dc.data_ptr(), gates.data_ptr(), c_prev.data_ptr(), c_cur.data_ptr(), B, H,
+                                            dpre_out.data_ptr(), _stream()), "vfr_lstm_cell_backward_f32")
 
 
 def ranking_loss_forward(posit, intra, inter, lang, maskp, maskn, n_samples: int, b: float, lamb: float, eps: float = 1e-6):

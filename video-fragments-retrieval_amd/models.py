@@ -6,8 +6,10 @@ Dispatch inside ``forward``:
 * ``model.eval()`` under ``torch.no_grad()`` with the input on a ROCm device  ->  the hand-written gfx950
   kernels (``_vfr``): chain-GEMM clip MLP, gather + BiLSTM + ``lang_fc`` query encoder.  If ``libvfr.so`` is
   missing this raises -- there is no silent substitute for the HIP path.
-* training mode or grad enabled  ->  the ``torch.nn`` sub-modules, because autograd must flow through the
-  model for ``main.py:66`` (training is the caller of the drop-in, not part of the accelerated path).
+* training mode or grad enabled, input on a ROCm device  ->  the same arithmetic as ``torch.autograd.Function``s whose
+  forward AND backward are HIP kernels (``train.py``: chain GEMMs + ``csrc/train.hip``), so ``loss.backward()`` of
+  ``main.py:66`` runs on our kernels too; ``models.HIP_TRAINING = False`` switches this path back to the ``torch.nn``
+  sub-modules (A/B checks).
 * input on the CPU  ->  the same ``torch.nn`` sub-modules (an ``nn.Module`` has to run where its tensors
   live; BASELINE config 0 is a CPU run).
 
@@ -23,6 +25,7 @@ import torch.nn as nn
 from .data import EMBEDDING_DIM
 
 _LSTM_KEYS = ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")
+HIP_TRAINING = True      # grad-enabled / training-mode forward on a ROCm device through the HIP autograd functions (train.py)
 
 
 def init_weights(m):
@@ -65,6 +68,9 @@ class CALModel(nn.Module):
     def _use_hip(self, t: torch.Tensor) -> bool:
         return t.is_cuda and not self.training and not torch.is_grad_enabled()
 
+    def _use_hip_train(self, t: torch.Tensor) -> bool:
+        return t.is_cuda and HIP_TRAINING and (self.training or torch.is_grad_enabled())
+
     def _lstm_weights(self):
         sd = {k: getattr(self.lstm, k) for k in _LSTM_KEYS}
         sd.update({k + "_reverse": getattr(self.lstm, k + "_reverse") for k in _LSTM_KEYS})
@@ -80,11 +86,18 @@ class CALModel(nn.Module):
                 h = _vfr.linear(x, fc1.weight.detach(), fc1.bias.detach(), relu=True)
                 out = _vfr.linear(h, fc2.weight.detach(), fc2.bias.detach())
                 return out.reshape(*batch.shape[:-1], out.shape[-1])
+            if self._use_hip_train(batch):
+                from . import train
+                fc1, fc2 = self.visual_fc[0], self.visual_fc[2]
+                return self.visual_fc[3](train.visual_mlp(batch.float(), fc1.weight, fc1.bias, fc2.weight, fc2.bias))
             return self.visual_fc(batch)
         if bert:
             if self._use_hip(batch):
                 from . import _vfr
                 return _vfr.linear(batch.float(), self.lang_fc.weight.detach(), self.lang_fc.bias.detach())
+            if self._use_hip_train(batch):
+                from . import train
+                return train.linear(batch.float(), self.lang_fc.weight, self.lang_fc.bias)
             return self.lang_fc(batch)
         if self._use_hip(batch):
             return self.encode_queries(batch)
@@ -92,6 +105,9 @@ class CALModel(nn.Module):
         if self.normalize_lang:
             length = self.learnable_length(batch)
             embedded = embedded.div(embedded.norm(dim=-1, keepdim=True) + 1e-5) * length
+        if self._use_hip_train(batch):
+            from . import train
+            return train.linear(train.bilstm_final(embedded, self.lstm), self.lang_fc.weight, self.lang_fc.bias)
         _, hidden = self.lstm(embedded, self.init_hidden(batch.size(0), device))
         h_n = hidden[0].transpose(0, 1).reshape(batch.size(0), 2 * self.hidden_size)
         return self.lang_fc(h_n)
