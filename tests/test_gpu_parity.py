@@ -869,3 +869,29 @@ def test_encoder_backward_hip_full_size_vs_torch_autograd(vfr):
     for name, want in res[False][2].items():
         scale = max(1.0, float(want.abs().max()))
         assert float((res[True][2][name] - want).abs().max()) <= 2e-4 * scale, name
+
+
+@pytest.mark.gpu
+def test_extractor_front_end_to_pooled_dataset(vfr, oracle, tmp_path):
+    """f4 -> a2 -> a3 end to end: decoded frames -> frame sampling (get_rgb_features.py:45-60) -> HIP VGG stack -> one .npy per
+    video (:150-151) -> data.CustomDataset pooling them (model/data.py:163-181).  The selected frames' features == the oracle's
+    VGG on exactly the frames the reference's index arithmetic selects; reduced width for speed."""
+    from vfr_amd import data as vdata, features
+    cfg = SMALL_VGG
+    cw, cb, fc6, fc7 = synth.vgg_weights(cfg, (32, 32), 64, seed=2)
+    weights = ([dev(w) for w in cw], [dev(b) for b in cb], (dev(fc6[0]), dev(fc6[1])), (dev(fc7[0]), dev(fc7[1])))
+    rs = np.random.RandomState(4)
+    clips = {"a": (rs.randint(0, 256, (150, 32, 32, 3)).astype(np.uint8), 5.0, 6),     # 30 s at 5 fps: all frames kept? no: 150 of 150
+             "b": (rs.randint(0, 256, (819, 32, 32, 3)).astype(np.uint8), 30.0, 6),    # 27.3 s at 30 fps -> 138 frames
+             "c": (rs.randint(0, 256, (625, 32, 32, 3)).astype(np.uint8), 25.0, 5)}
+    info = [dict(video=k, num_segments=v[2]) for k, v in clips.items()] + [dict(video="broken", num_segments=6)]
+    decoder = lambda video, nseg: (None, 0) if video == "broken" else clips[video][:2]
+    ft = tmp_path / "features_vgg19"
+    written, missed = features.extract_dataset(info, decoder, ft, weights, cfg=cfg, missed_path=tmp_path / "missed.json")
+    assert written == ["a", "b", "c"] and missed == ["broken"]
+    for name, (frames, fps, nseg) in clips.items():
+        got = np.load(ft / f"vgg19_ft_{name}.npy")
+        mask = oracle.frame_sample_indices(len(frames), fps, nseg)
+        want = oracle.vgg_fc7(frames[mask], cw, cb, fc6, fc7, cfg)
+        assert got.shape == want.shape and np.array_equal(got, want), name
+    assert np.load(ft / "vgg19_ft_b.npy").shape[0] == 138

@@ -331,3 +331,45 @@ def _encoder_grad_case(tag, device, golden):
 def test_encoder_gradients_cpu_device_match_reference(golden, tag):
     """f2 second half, CPU device: loss.backward() through CALModel (torch.nn path) == the reference's gradients (G10)."""
     _encoder_grad_case(tag, "cpu", golden)
+
+
+def test_frame_sampling_matches_reference_arithmetic(oracle):
+    """f4: get_rgb_features.py:45-60 -- the vectorised index selection == the reference's running-step loop (oracle
+    restatement) over frame counts / frame rates / segment counts, and the counts SURVEY 3.1 derived from it."""
+    from vfr_amd import features
+    assert len(features.sample_frames(900, 30.0, 6)) == 150 and len(features.sample_frames(750, 30.0, 5)) == 125
+    assert len(features.sample_frames(819, 30.0, 6)) == 138                      # 27.3 s: the last clip pools 13 frames
+    assert features.sample_frames(0, 30.0, 6).tolist() == []
+    rs = np.random.RandomState(0)
+    for _ in range(1500):
+        fps = float(rs.choice([23.976, 24.0, 25.0, 29.97, 30.0, 15.0, 59.94, 12.5]))
+        nseg = int(rs.randint(1, 7))
+        nf = int(rs.randint(1, int(fps * 5 * nseg) + 2))
+        got = features.sample_frames(nf, fps, nseg)
+        assert got.tolist() == oracle.frame_sample_indices(nf, fps, nseg), (nf, fps, nseg)
+        assert got.dtype == np.int64 and (np.diff(got) >= 0).all() and got.max() < max(nf, 1)
+
+
+def test_extract_dataset_resume_and_missed_bookkeeping(tmp_path, monkeypatch):
+    """f4: the extraction loop's skip-done / skip-missed / record-unreadable behaviour (get_rgb_features.py:105-116,152-156)
+    with the device pass stubbed out (this is the host logic)."""
+    from vfr_amd import features
+    calls = []
+
+    def fake_extract(frames, fps, nseg, weights, cfg=None):
+        calls.append((len(frames), fps, nseg))
+        return torch.full((len(features.sample_frames(len(frames), fps, nseg)), 4), float(nseg))
+    monkeypatch.setattr(features, "extract_video", fake_extract)
+    info = [dict(video=f"v{i}", num_segments=6 if i % 2 else 5) for i in range(5)]
+    ft = tmp_path / "features"
+    ft.mkdir()
+    np.save(ft / "vgg19_ft_v1", np.zeros((3, 4), np.float32))                   # already done
+    missed_file = tmp_path / "missed_videos_features.json"
+    missed_file.write_text(json.dumps(["v2"]))                                  # known unreadable
+    decoder = lambda video, nseg: (None, 0) if video == "v3" else (np.zeros((25 * 5 * nseg, 2, 2, 3), np.uint8), 25.0)
+    written, missed = features.extract_dataset(info, decoder, ft, None, missed_path=missed_file)
+    assert written == ["v0", "v4"] and missed == ["v2", "v3"] and json.loads(missed_file.read_text()) == ["v2", "v3"]
+    assert np.load(ft / "vgg19_ft_v0.npy").shape == (125, 4) and np.load(ft / "vgg19_ft_v1.npy").shape == (3, 4)
+    assert calls == [(625, 25.0, 5), (625, 25.0, 5)]
+    with pytest.raises(NotImplementedError):
+        features.extract_dataset(info, decoder, ft, None, model_type="resnet152", missed_path=missed_file)
