@@ -895,3 +895,24 @@ def test_extractor_front_end_to_pooled_dataset(vfr, oracle, tmp_path):
         want = oracle.vgg_fc7(frames[mask], cw, cb, fc6, fc7, cfg)
         assert got.shape == want.shape and np.array_equal(got, want), name
     assert np.load(ft / "vgg19_ft_b.npy").shape[0] == 138
+
+
+@pytest.mark.gpu
+def test_mfma_prefilter_centres_offset_embeddings(vfr):
+    """Embeddings that share a large common offset (norms 40x the distances): the pre-filter's margins are taken for the
+    CENTRED rows, so it still answers itself -- no fallback group, a small exact fraction -- with the exact kernels' bits."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    nv, nq, n, k = 2000, 300, 21, 100
+    V = torch.randn((nv * n, 100), device=DEV, generator=g) * 0.1 + 4.0
+    Q = torch.randn((nq, 100), device=DEV, generator=g) * 0.1 + 4.0
+    off = torch.arange(0, nv * n + 1, n, dtype=torch.int32, device=DEV)
+    bank = vfr.VideoBank(V, off)
+    d0, i0, _ = vfr.score_topk(Q, bank, k, mode="exact")
+    rd = torch.stack([d0[:, 30], d0[:, 99] * 1.02]).contiguous()
+    ri = torch.stack([i0[:, 30], i0[:, 99]]).contiguous()
+    d0, i0, c0 = vfr.score_topk(Q, bank, k, rd, ri, mode="exact")
+    ws = vfr.topk_workspace(nq, nv, k, DEV, total_clips=nv * n)
+    d1, i1, c1 = vfr.score_topk(Q, bank, k, rd, ri, workspace=ws, mode="mfma")
+    st = vfr.score_mfma_stats(ws, nq, bank, k)
+    assert st["fallback_groups"] == 0 and st["exact_pair_fraction"] < 0.3, st
+    assert torch.equal(i0, i1) and torch.equal(d0, d1) and torch.equal(c0, c1) and bool((c0[0] == 30).all())

@@ -18,13 +18,13 @@ dev = torch.device("cuda", 0)
 _vfr.set_option("score_mfma_min", 0)                  # small cases must exercise the pre-filter kernels
 
 
-def run(nv, nq, clips, k, scale=0.1, seed=0, reps=3):
+def run(nv, nq, clips, k, scale=0.1, seed=0, reps=3, offset=0.0):
     g = torch.Generator(device=dev).manual_seed(seed)
     rs = np.random.RandomState(seed)
     counts = np.full(nv, clips) if isinstance(clips, int) else rs.choice([5, 6], nv)
     off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-    V = torch.randn((int(off[-1]), 100), device=dev, generator=g) * scale
-    Q = torch.randn((nq, 100), device=dev, generator=g) * scale
+    V = torch.randn((int(off[-1]), 100), device=dev, generator=g) * scale + offset     # offset: a common shift of every embedding
+    Q = torch.randn((nq, 100), device=dev, generator=g) * scale + offset
     bank = _vfr.VideoBank(V, torch.from_numpy(off).to(dev))
     ws = _vfr.topk_workspace(nq, nv, k, dev, total_clips=int(off[-1]))
     # rank keys: two mid-distribution moments per query (scores of random moments of random videos)
@@ -69,7 +69,7 @@ if __name__ == "__main__":
         cases = [(nv, nq, clips, k)]
     else:
         cases = [(1, 1, 6, 10), (3, 65, 21, 100), (40, 130, 21, 100), (300, 64, 6, 100), (700, 200, "didemo", 50),
-                 (2500, 500, 21, 100), (10000, 5000, 21, 100)]
+                 (2500, 500, 21, 100), (10000, 5000, 21, 100), (2000, 300, 21, 100, 0.1, 3, 2, 4.0)]
     allok = True
     for c in cases:
         print(c)

@@ -1395,6 +1395,7 @@ namespace vfr {
 struct MfmaWs {
     float *rv; int *fallback; int *queue_cnt; unsigned long long *cnt_ws; size_t zero_bytes; char *zero_base;
     float *va; float4 *qmeta; unsigned *tab; unsigned short *vb; unsigned long long *queue; int queue_cap; int tasks, groups;
+    float *mu, *vc, *qc; double *mean_partial; int mean_blocks, mean_rows;
     void *topk; size_t topk_bytes; size_t total;
 };
 static MfmaWs carve_mfma(void *base, int64_t Nq, int Nv, int total_clips, int k)
@@ -1414,6 +1415,12 @@ static MfmaWs carve_mfma(void *base, int64_t Nq, int Nv, int total_clips, int k)
     w.queue_cnt = reinterpret_cast<int *>(take((size_t)w.tasks * 4));
     w.cnt_ws = reinterpret_cast<unsigned long long *>(take((size_t)MAX_RANK * Nq * 8));
     w.zero_bytes = off;
+    w.mean_rows = 512;
+    w.mean_blocks = (int)cdiv(total_clips > 0 ? total_clips : 1, w.mean_rows);
+    w.mu = reinterpret_cast<float *>(take(128 * 4));
+    w.mean_partial = reinterpret_cast<double *>(take((size_t)w.mean_blocks * 128 * 8));
+    w.vc = reinterpret_cast<float *>(take((size_t)total_clips * FAST_D * 4));
+    w.qc = reinterpret_cast<float *>(take((size_t)Nq * FAST_D * 4));
     w.va = reinterpret_cast<float *>(take((size_t)total_clips * 4));
     w.qmeta = reinterpret_cast<float4 *>(take((size_t)Nq * 16));
     w.tab = reinterpret_cast<unsigned *>(take((size_t)Nq * 2 * 21 * MF_TAB * 4));
@@ -1483,19 +1490,22 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
     if (hipMemsetAsync(mw.zero_base, 0, mw.zero_bytes, st) != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: hipMemsetAsync failed");
     vfr::MfmaArgs m{};
     m.va = mw.va; m.qmeta = mw.qmeta; m.tab = mw.tab; m.cnt_ws = mw.cnt_ws; m.queue = mw.queue; m.queue_cnt = mw.queue_cnt;
-    m.queue_cap = mw.queue_cap; m.fallback = mw.fallback; m.vb = bf16 ? mw.vb : nullptr; m.rv = mw.rv;
+    m.queue_cap = mw.queue_cap; m.fallback = mw.fallback; m.vb = bf16 ? mw.vb : nullptr; m.rv = mw.rv; m.vc = mw.vc; m.qc = mw.qc;
     {
         vfr::ProfScope prof(vfr::SITE_SCORE_PREP, st);
+        hipLaunchKernelGGL(vfr::mfma_mean_partial_kernel, dim3((unsigned)mw.mean_blocks), dim3(1024), 0, st, V, total_clips, D, mw.mean_rows,
+                           mw.mean_partial);
+        hipLaunchKernelGGL(vfr::mfma_mean_final_kernel, dim3(1), dim3(1024), 0, st, mw.mean_partial, mw.mean_blocks, D, total_clips, mw.mu);
         hipLaunchKernelGGL(vfr::mfma_prep_v_kernel, dim3((unsigned)vfr::cdiv(total_clips, 4)), dim3(256), 0, st, V, total_clips, D, eps,
-                           mw.va, mw.rv, bf16 ? mw.vb : nullptr);
-        hipLaunchKernelGGL(vfr::mfma_prep_q_kernel, dim3((unsigned)vfr::cdiv(Nq, 64)), dim3(64), 0, st, Q, Nq, D, eps, mw.rv, num_rank, rank_dist,
-                           mw.qmeta);
+                           mw.mu, mw.vc, mw.va, mw.rv, bf16 ? mw.vb : nullptr);
+        hipLaunchKernelGGL(vfr::mfma_prep_q_kernel, dim3((unsigned)vfr::cdiv(Nq, 64)), dim3(64), 0, st, Q, Nq, D, eps, mw.mu, mw.qc, mw.rv,
+                           num_rank, rank_dist, mw.qmeta);
         if (num_rank > 0) {
             const dim3 tg((unsigned)vfr::cdiv(Nq * num_rank * NT, 256));
             if (NT == 6)
-                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<6>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0);
+                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<6>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0, mw.fallback);
             else
-                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<21>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0);
+                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<21>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0, mw.fallback);
         }
         if (k > 0) {
             if (thr_seed)

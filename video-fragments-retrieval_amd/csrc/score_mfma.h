@@ -31,6 +31,10 @@
 //     obeys |d - d*| <= 53.5 u d*;  v_sqrt_f32 on the approximate side adds 2 u d~.
 //   * sums of L distances add (L - 1) u S on either side.
 //   => |S~ - S| <= L E2 / dfl + (56 + 2 L) u S  =: Delta_L   for every moment of a pair whose clips all have d~ >= dfl.
+// Centring.  The distance is translation invariant and E2 grows with the squared NORMS, so the GEMM runs on v - mu, q - mu
+// (mu = the mean clip embedding, rounded once per element): embeddings that share a large common offset lose it, R and |q|
+// above are the norms of the centred rows, and the two roundings move a distance by at most u (R + |q|) -- added to Delta_L.
+// The exact paths read the original rows.
 // dfl = 3/4 of the smaller rank-key distance of the query (per-query constant); for the top-k check the floor is the best
 // approximate score itself (no clip is closer to the query than the best single-clip moment).
 //
@@ -47,7 +51,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct MfmaArgs {
     const float *va;                         // [total_clips] a_c
-    const float4 *qmeta;                     // [Nq] {b_q, dfl, E2, |q|}
+    const float4 *qmeta;                     // [Nq] {b_q, dfl, E2, R + |q|} (centred norms)
     const unsigned *tab;                     // [Nq][NR][NT][MF_TAB]
     unsigned long long *cnt_ws;              // [NR][Nq] rank counts of this call (committed to count_lt at the end)
     unsigned long long *queue;               // [tasks][queue_cap] ambiguous pairs: query << 32 | video << 2 | key mask
@@ -55,14 +59,57 @@ struct MfmaArgs {
     int queue_cap;
     int *fallback;                           // [groups] != 0: answered by the exact kernels
     const unsigned short *vb;                // bf16 mode: V as bf16 [total_clips][128] (zero padded)
-    const float *rv;                         // [1] max clip norm (pre-pass)
+    const float *rv;                         // [1] max norm of the CENTRED clip rows (pre-pass)
+    const float *vc, *qc;                    // V - mu [total_clips, D], Q - mu [Nq, D]: the operands of the approximate GEMM
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
 // pre-passes
 // ---------------------------------------------------------------------------------------------------------------------
-// one wave per clip row: a_c in fp64, max norm (float atomicMax on the bits: norms are >= 0), optional bf16 copy
+// mean clip embedding mu [D] (D <= 128), two deterministic stages: 1024-thread blocks sum a slice of rows (thread = column x
+// row phase, fp64), then one 1024-thread block adds the per-block partials (8 slices per column)
+__global__ __launch_bounds__(1024) void mfma_mean_partial_kernel(const float *__restrict__ V, int total_clips, int D, int rows_per_block,
+                                                                 double *__restrict__ partial)
+{
+    __shared__ double red[1024];
+    const int k = threadIdx.x & 127, ph = threadIdx.x >> 7;              // column, row phase (8)
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    r1 = r1 < total_clips ? r1 : total_clips;
+    double acc = 0.0;
+    if (k < D)
+        for (int64_t r = r0 + ph; r < r1; r += 8) acc += V[r * D + k];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (ph == 0 && k < D) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i * 128 + k];
+        partial[(int64_t)blockIdx.x * D + k] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void mfma_mean_final_kernel(const double *__restrict__ partial, int nblocks, int D, int total_clips,
+                                                               float *__restrict__ mu)
+{
+    __shared__ double red[1024];
+    const int k = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    double acc = 0.0;
+    if (k < D)
+        for (int b = sl; b < nblocks; b += 8) acc += partial[(int64_t)b * D + k];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (sl == 0 && k < D) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i * 128 + k];
+        mu[k] = (float)(t / (double)(total_clips > 0 ? total_clips : 1));
+    }
+}
+
+// one wave per clip row: the centred row v - mu (fp32, what the MFMAs read), its a_c in fp64, the largest centred norm
+// (float atomicMax on the bits: norms are >= 0), optional bf16 copy
 __global__ __launch_bounds__(256) void mfma_prep_v_kernel(const float *__restrict__ V, int total_clips, int D, float eps,
+                                                          const float *__restrict__ mu, float *__restrict__ vc,
                                                           float *__restrict__ va, float *__restrict__ rv,
                                                           unsigned short *__restrict__ vb)
 {
@@ -71,7 +118,12 @@ __global__ __launch_bounds__(256) void mfma_prep_v_kernel(const float *__restric
     if (row >= total_clips) return;
     const float *v = V + row * D;
     double s2 = 0.0, s1 = 0.0;
-    for (int k = lane; k < D; k += 64) { const double x = v[k]; s2 += x * x; s1 += x; }
+    for (int k = lane; k < D; k += 64) {
+        const float c = v[k] - mu[k];
+        vc[row * D + k] = c;
+        const double x = c;
+        s2 += x * x; s1 += x;
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { s2 += __shfl_xor(s2, o, 64); s1 += __shfl_xor(s1, o, 64); }
     if (lane == 0) {
@@ -83,13 +135,14 @@ __global__ __launch_bounds__(256) void mfma_prep_v_kernel(const float *__restric
     }
     if (vb)
         for (int k = lane; k < 128; k += 64) {
-            const __bf16 b = (__bf16)(k < D ? v[k] : 0.0f);
+            const __bf16 b = (__bf16)(k < D ? v[k] - mu[k] : 0.0f);
             vb[row * 128 + k] = __builtin_bit_cast(unsigned short, b);
         }
 }
 
 // one thread per query: b_q, |q|, E2, the distance floor
 __global__ __launch_bounds__(64) void mfma_prep_q_kernel(const float *__restrict__ Q, int64_t Nq, int D, float eps,
+                                                         const float *__restrict__ mu, float *__restrict__ qc,
                                                          const float *__restrict__ rv, int NR,
                                                          const float *__restrict__ rank_dist, float4 *__restrict__ qmeta)
 {
@@ -97,25 +150,32 @@ __global__ __launch_bounds__(64) void mfma_prep_q_kernel(const float *__restrict
     if (q >= Nq) return;
     const float *p = Q + q * D;
     double s2 = 0.0, s1 = 0.0;
-    for (int k = 0; k < D; ++k) { const double x = p[k]; s2 += x * x; s1 += x; }
+    for (int k = 0; k < D; ++k) {
+        const float c = p[k] - mu[k];
+        qc[q * D + k] = c;
+        const double x = c;
+        s2 += x * x; s1 += x;
+    }
     const float bq = (float)(s2 - 2.0 * (double)eps * s1);
     const float qn = (float)__builtin_sqrt(s2) * 1.0000002f;
     const float R = *rv;
     // G bounds every partial sum of the approximate chain: (R + |q|)^2 + 2 eps sqrt(D) (R + |q|) + D eps^2, rounded up
     const float rs = (R + qn) * 1.000001f;
     const float G = (rs * rs + 2.0f * eps * __builtin_sqrtf((float)D) * rs + (float)D * eps * eps) * 1.00001f;
+    // E2 bounds |d~^2 - d'^2| for the CENTRED rows; the centring roundings themselves move a distance by <= u (R + |q|),
+    // which the table kernel and the finisher add per clip (qmeta.w = R + |q|)
     const float E2 = 20.0f * MF_U * G;
     float xmin = __builtin_inff();
     for (int r = 0; r < NR; ++r) { const float x = rank_dist[r * Nq + q]; xmin = x < xmin ? x : xmin; }
     const float dfl = NR > 0 && xmin < __builtin_inff() ? 0.75f * xmin : 0.0f;
-    qmeta[q] = make_float4(bq, dfl, E2, qn);
+    qmeta[q] = make_float4(bq, dfl, E2, rs);
 }
 
 // one thread per (query, rank key, span length): the exact bit bounds of the sum and their widened forms
 template <int NT>
 __global__ __launch_bounds__(256) void mfma_prep_tab_kernel(int64_t Nq, int NR, const float *__restrict__ rank_dist,
                                                             const float4 *__restrict__ qmeta, unsigned *__restrict__ tab,
-                                                            int bf16_mode)
+                                                            int bf16_mode, int *__restrict__ fallback)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= Nq * NR * NT) return;
@@ -131,7 +191,7 @@ __global__ __launch_bounds__(256) void mfma_prep_tab_kernel(int64_t Nq, int NR, 
     if (!bf16_mode && x < __builtin_inff()) {
         // Delta_L: see the header.  S is at most hi + Delta_L near the window; (56 + 2L) u S with 2 % head-room.
         const float Sref = (hi > 0.0f ? hi : 0.0f) + (float)L * 1e-3f;
-        const float delta = dfl > 0.0f ? ((float)L * E2 / dfl + (float)(56 + 2 * L) * MF_U * Sref * 1.02f) * 1.0001f
+        const float delta = dfl > 0.0f ? ((float)L * (E2 / dfl + MF_U * meta.w * 1.01f) + (float)(56 + 2 * L) * MF_U * Sref * 1.02f) * 1.0001f
                                        : __builtin_inff();
         float low = lo - delta;                                           // lo = -1: no sum is below the key
         low = low > 0.0f ? next_down(low) : -1.0f;
@@ -143,6 +203,9 @@ __global__ __launch_bounds__(256) void mfma_prep_tab_kernel(int64_t Nq, int NR, 
         if (LOW > LOX) LOW = LOX;
     }
     *reinterpret_cast<uint4 *>(t) = make_uint4(LOX, HIX, LOW, HIW - LOW);
+    // a window wider than the kernel's 10-bit field (a key distance near zero, norms far above the distances): the query's
+    // group goes to the exact kernels right away -- the pre-filter kernel returns at once for a flagged group
+    if (!bf16_mode && HIW - LOW > 1023u) fallback[q >> 6] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -167,6 +230,10 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
 
     const int64_t qi = (int64_t)group * 64 + lane;
     const bool active = qi < a.Nq;
+    if (!BF16 && m.fallback[group]) {                                     // this group is answered by the exact kernels
+        if (TOPK) a.buf_cnt[(size_t)task * 64 + lane] = 0;
+        return;
+    }
     const float4 meta = m.qmeta[active ? qi : a.Nq - 1];
     const float bq = meta.x, dfl = (active && !BF16) ? meta.y : 0.0f;
 
@@ -177,7 +244,7 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
     for (int t = 0; t < 4; ++t) {
         int64_t row = (int64_t)group * 64 + 16 * t + j;
         row = row < a.Nq ? row : a.Nq - 1;
-        const float *p = Qp + row * FAST_D;
+        const float *p = m.qc + row * FAST_D;
         if constexpr (!BF16) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -240,7 +307,7 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
     bf16x8 Bb[BF16 ? 4 : 1];
     float acv_next = 0.0f;
     auto brow = [&](int64_t c_tile) -> int64_t { const int64_t row = c_tile + j; return row < last_row ? row : last_row; };
-    auto bblock = [&](int64_t row, int b) -> float4 { return *reinterpret_cast<const float4 *>(Vp + row * FAST_D + 24 * g + 4 * b); };
+    auto bblock = [&](int64_t row, int b) -> float4 { return *reinterpret_cast<const float4 *>(m.vc + row * FAST_D + 24 * g + 4 * b); };
     auto bload_bf16 = [&](int64_t c_tile) {
         const int64_t row = brow(c_tile);
         acv_next = m.va[row];
@@ -267,7 +334,7 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
     else {
         const int64_t row = brow(c_lo);
         acv_next = m.va[row];
-        Bl_next = Vp[row * FAST_D + 96 + g];
+        Bl_next = m.vc[row * FAST_D + 96 + g];
 #pragma unroll
         for (int b = 0; b < 3; ++b) Bq[b] = bblock(row, b);
     }
@@ -297,7 +364,7 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
 #endif
                 }
                 Bq[b % 3] = b < 3 ? bblock(row, b + 3) : bblock(row_n, b - 3);
-                if (b == 3) { Bl_next = Vp[row_n * FAST_D + 96 + g]; acv_next = m.va[row_n]; }
+                if (b == 3) { Bl_next = m.vc[row_n * FAST_D + 96 + g]; acv_next = m.va[row_n]; }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[t] = b == 0 ? part[t] : acc[t] + part[t];
             }
@@ -755,7 +822,7 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const unsigned long lo
             const float s1 = __uint_as_float((unsigned)(a1 >> 32)), sk = __uint_as_float((unsigned)(ak >> 32)),
                         sK = __uint_as_float((unsigned)(aK >> 32));
             const float E2 = qmeta[q].z;
-            const float delta = (s1 > 0.0f ? E2 / s1 : __builtin_inff()) + 190.0f * MF_U * sK * 1.02f;
+            const float delta = (s1 > 0.0f ? E2 / s1 : __builtin_inff()) + MF_U * qmeta[q].w * 1.01f + 190.0f * MF_U * sK * 1.02f;
             if (!(sK > sk + 2.0f * delta * 1.0001f) && lane == 0) fallback[q >> 6] = 1;
         }
         if (thr_seed && a1 != KEY_MAX) {
