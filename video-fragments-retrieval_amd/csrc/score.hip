@@ -1498,7 +1498,7 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
         hipLaunchKernelGGL(vfr::mfma_mean_final_kernel, dim3(1), dim3(1024), 0, st, mw.mean_partial, mw.mean_blocks, D, total_clips, mw.mu);
         hipLaunchKernelGGL(vfr::mfma_prep_v_kernel, dim3((unsigned)vfr::cdiv(total_clips, 4)), dim3(256), 0, st, V, total_clips, D, eps,
                            mw.mu, mw.vc, mw.va, mw.rv, bf16 ? mw.vb : nullptr);
-        hipLaunchKernelGGL(vfr::mfma_prep_q_kernel, dim3((unsigned)vfr::cdiv(Nq, 64)), dim3(64), 0, st, Q, Nq, D, eps, mw.mu, mw.qc, mw.rv,
+        hipLaunchKernelGGL(vfr::mfma_prep_q_kernel, dim3((unsigned)vfr::cdiv(Nq, 16)), dim3(256), 0, st, Q, Nq, D, eps, mw.mu, mw.qc, mw.rv,
                            num_rank, rank_dist, mw.qmeta);
         if (num_rank > 0) {
             const dim3 tg((unsigned)vfr::cdiv(Nq * num_rank * NT, 256));

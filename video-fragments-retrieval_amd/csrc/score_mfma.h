@@ -140,22 +140,27 @@ __global__ __launch_bounds__(256) void mfma_prep_v_kernel(const float *__restric
         }
 }
 
-// one thread per query: b_q, |q|, E2, the distance floor
-__global__ __launch_bounds__(64) void mfma_prep_q_kernel(const float *__restrict__ Q, int64_t Nq, int D, float eps,
-                                                         const float *__restrict__ mu, float *__restrict__ qc,
-                                                         const float *__restrict__ rv, int NR,
-                                                         const float *__restrict__ rank_dist, float4 *__restrict__ qmeta)
+// 16 lanes per query (coalesced row reads, fp64 shuffle reduction): the centred row q - mu, b_q, E2, the distance floor
+__global__ __launch_bounds__(256) void mfma_prep_q_kernel(const float *__restrict__ Q, int64_t Nq, int D, float eps,
+                                                          const float *__restrict__ mu, float *__restrict__ qc,
+                                                          const float *__restrict__ rv, int NR,
+                                                          const float *__restrict__ rank_dist, float4 *__restrict__ qmeta)
 {
-    const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (q >= Nq) return;
-    const float *p = Q + q * D;
+    const int sub = threadIdx.x & 15;
+    const int64_t q = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool on = q < Nq;
+    const float *p = Q + (on ? q : 0) * D;
     double s2 = 0.0, s1 = 0.0;
-    for (int k = 0; k < D; ++k) {
-        const float c = p[k] - mu[k];
-        qc[q * D + k] = c;
-        const double x = c;
-        s2 += x * x; s1 += x;
-    }
+    if (on)
+        for (int k = sub; k < D; k += 16) {
+            const float c = p[k] - mu[k];
+            qc[q * D + k] = c;
+            const double x = c;
+            s2 += x * x; s1 += x;
+        }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) { s2 += __shfl_xor(s2, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    if (!on || sub != 0) return;
     const float bq = (float)(s2 - 2.0 * (double)eps * s1);
     const float qn = (float)__builtin_sqrt(s2) * 1.0000002f;
     const float R = *rv;
