@@ -214,11 +214,19 @@ int vfr_ranking_loss_grad_f32(const float *posit, const float *intra, const floa
  * model/models.py:21-26 (visual_fc) and :40-47,61-66 (lstm, lang_fc).  The gradient contractions are vfr_linear_f32 on
  * transposed operands (dX = dY W, dW = dY^T X); these are the pieces around them (train.py wires them into autograd):
  *   transpose      out [cols, rows] = in [rows, cols]^T
- *   colsum         out[c] = sum_r in[r][c], rows in ascending order (bias gradients; deterministic)
+ *   colsum         out[c] = sum_r in[r][c] in a fixed order (16 row phases, then the phases; bias gradients; deterministic)
  *   relu_backward  out = act > 0 ? grad : 0
  *   lstm_cell_forward   one step of nn.LSTM's cell (gates i, f, g, o): pre [B,4H] = h_prev W_hh^T + b_hh, the input part
  *                  x_t W_ih^T + b_ih of batch row b at xproj + b * x_stride; writes the ACTIVATED gates [B,4H], c, h [B,H]
- *   lstm_cell_backward  one step of BPTT: (dh [B,H], dc [B,H] in/out) + the step's gates and cell states -> dpre [B,4H]   */
+ *   lstm_cell_backward  one step of BPTT: (dh [B,H], dc [B,H] in/out) + the step's gates and cell states -> dpre [B,4H]
+ *   bilstm_train_forward   the whole recurrence of both directions over dense inputs X [B,T,E] (E, H multiples of 4): T
+ *                  launches of the inference path's fused step, which here also stores the activated gates.  Buffers are
+ *                  [direction][step]-major: gates [2][T][B][4H], cs / hs [2][T+1][B][H] (slot 0 = the zero initial state,
+ *                  written here; step s of the reverse direction read time T-1-s); h_n = hs[d][T].
+ *   bilstm_train_backward  BPTT for both directions: gout [B,2H] = gradient of [h_fwd | h_bwd]; WhhT_d [H,4H] = W_hh,d^T;
+ *                  dpre [2][T][B][4H] = gradient of every step's gate pre-activations (the weight gradients are GEMMs over
+ *                  it).  Per step one cell-backward launch and one GEMM grid for both directions, K cut into ranges whose
+ *                  partial products the next cell-backward adds in a fixed order (deterministic).                          */
 int vfr_transpose_f32(const float *in, int64_t rows, int64_t cols, float *out, vfr_stream_t stream);
 int vfr_colsum_f32(const float *in, int64_t rows, int cols, float *out, vfr_stream_t stream);
 int vfr_relu_backward_f32(const float *grad, const float *act, int64_t n, float *out, vfr_stream_t stream);
@@ -226,6 +234,12 @@ int vfr_lstm_cell_forward_f32(const float *pre, const float *xproj, int64_t x_st
                               float *gates, float *c, float *h, vfr_stream_t stream);
 int vfr_lstm_cell_backward_f32(const float *dh, float *dc, const float *gates, const float *c_prev, const float *c_cur, int64_t B,
                                int H, float *dpre, vfr_stream_t stream);
+int vfr_bilstm_train_forward_f32(const float *X, int64_t B, int T, int E, int H, const float *Wih_f, const float *Whh_f,
+                                 const float *bih_f, const float *bhh_f, const float *Wih_b, const float *Whh_b,
+                                 const float *bih_b, const float *bhh_b, float *gates, float *cs, float *hs, vfr_stream_t stream);
+size_t vfr_bilstm_train_backward_workspace_bytes(int64_t B, int H);
+int vfr_bilstm_train_backward_f32(const float *gout, const float *gates, const float *cs, const float *WhhT_f, const float *WhhT_b,
+                                  int64_t B, int T, int H, float *dpre, void *workspace, size_t workspace_bytes, vfr_stream_t stream);
 
 /* ---- parity probe: elementwise canonical math (0 exp, 1 sigmoid, 2 tanh, 3 x/y, 4 sqrt,
  * 5 fma(x,y,x)) so tests can pin the device's transcendental forms against the oracle's.        */

@@ -872,6 +872,32 @@ def test_encoder_backward_hip_full_size_vs_torch_autograd(vfr):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T,E,H", [(37, 7, 12, 20), (300, 5, 8, 132), (9, 6, 10, 6), (5, 4, 12, 7)])
+def test_bilstm_training_paths_vs_torch_autograd(vfr, B, T, E, H):
+    """train.bilstm_final (fused recurrence: E, H multiples of 4; step-by-step kernels otherwise) vs nn.LSTM's autograd:
+    h_n 1e-5, gradients of the input and of all eight weights 1e-4 of their scale.  (300, 132) spans several row / column
+    tiles and several split-K ranges."""
+    from vfr_amd import train
+    torch.manual_seed(B * 131 + H)
+    lstm = torch.nn.LSTM(E, H, batch_first=True, bidirectional=True).to(DEV)
+    x = torch.randn(B, T, E, device=DEV)
+    w = torch.randn(B, 2 * H, device=DEV)
+    res = []
+    for hip in (True, False):
+        lstm.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        if hip:
+            hn = train.bilstm_final(xi, lstm)
+        else:
+            hn = lstm(xi)[1][0].permute(1, 0, 2).reshape(B, 2 * H)
+        (hn * w).sum().backward()
+        res.append((hn.detach(), xi.grad.clone(), {n: p.grad.clone() for n, p in lstm.named_parameters()}))
+    assert torch.allclose(res[0][0], res[1][0], rtol=0, atol=1e-5)
+    for got, want, name in [(res[0][1], res[1][1], "x")] + [(res[0][2][n], res[1][2][n], n) for n in res[1][2]]:
+        assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max())), name
+
+
+@pytest.mark.gpu
 def test_extractor_front_end_to_pooled_dataset(vfr, oracle, tmp_path):
     """f4 -> a2 -> a3 end to end: decoded frames -> frame sampling (get_rgb_features.py:45-60) -> HIP VGG stack -> one .npy per
     video (:150-151) -> data.CustomDataset pooling them (model/data.py:163-181).  The selected frames' features == the oracle's

@@ -60,6 +60,9 @@ SIGNATURES = {
     "vfr_relu_backward_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "vfr_lstm_cell_forward_f32": (_i32, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "vfr_lstm_cell_backward_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "vfr_bilstm_train_forward_f32": (_i32, [_vp, _i64, _i32, _i32, _i32] + [_vp] * 8 + [_vp, _vp, _vp, _vp]),
+    "vfr_bilstm_train_backward_workspace_bytes": (_sz, [_i64, _i32]),
+    "vfr_bilstm_train_backward_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vfr_frames_normalize_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "vfr_conv3x3_relu_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "vfr_maxpool2_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -503,6 +506,34 @@ def lstm_cell_backward(dh, dc, gates, c_prev, c_cur, dpre_out):
     B, H = c_prev.shape
     _check(lib().vfr_lstm_cell_backward_f32(dh.data_ptr(), dc.data_ptr(), gates.data_ptr(), c_prev.data_ptr(), c_cur.data_ptr(), B, H,
                                             dpre_out.data_ptr(), _stream()), "vfr_lstm_cell_backward_f32")
+
+
+def bilstm_train_forward(x, ws):
+    """x [B, T, E] f32, ws = the eight nn.LSTM tensors (forward four, reverse four) -> (gates [2,T,B,4H], cs, hs [2,T+1,B,H])."""
+    x = _dev(x, torch.float32, "x")
+    ws = [_dev(w, torch.float32, "lstm weight") for w in ws]
+    B, T, E = x.shape
+    H = ws[1].shape[1]
+    gates = torch.empty((2, T, B, 4 * H), dtype=torch.float32, device=x.device)
+    cs = torch.empty((2, T + 1, B, H), dtype=torch.float32, device=x.device)
+    hs = torch.empty((2, T + 1, B, H), dtype=torch.float32, device=x.device)
+    _check(lib().vfr_bilstm_train_forward_f32(x.data_ptr(), B, T, E, H, *[w.data_ptr() for w in ws], gates.data_ptr(), cs.data_ptr(),
+                                              hs.data_ptr(), _stream()), "vfr_bilstm_train_forward_f32")
+    return gates, cs, hs
+
+
+def bilstm_train_backward(gout, gates, cs, whhT_f, whhT_b):
+    """gout [B, 2H] -> dpre [2, T, B, 4H] (gradient of every step's gate pre-activations, step-major per direction)."""
+    gout = _dev(gout, torch.float32, "gout")
+    _, T, B, G = gates.shape
+    H = G // 4
+    nbytes = lib().vfr_bilstm_train_backward_workspace_bytes(B, H)
+    wsb = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=gout.device)
+    dpre = torch.empty_like(gates)
+    _check(lib().vfr_bilstm_train_backward_f32(gout.data_ptr(), gates.data_ptr(), cs.data_ptr(), whhT_f.data_ptr(), whhT_b.data_ptr(),
+                                               B, T, H, dpre.data_ptr(), wsb.data_ptr(), nbytes, _stream()),
+           "vfr_bilstm_train_backward_f32")
+    return dpre
 
 
 def ranking_loss_forward(posit, intra, inter, lang, maskp, maskn, n_samples: int, b: float, lamb: float, eps: float = 1e-6):

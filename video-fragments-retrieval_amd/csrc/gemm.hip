@@ -151,9 +151,10 @@ __device__ unsigned long long g_gemm_stamps[4];
 // work on that stall.
 // NARROW = 64-column workgroup tile, the four waves stacked along M (each wave still 16*TI x 64): for operands with N <= 64
 // (VGG conv1_1 / conv1_2), where the 128-column tile would spend half of every MFMA on columns that do not exist.
-template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false, bool NARROW = false>
+template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false, bool NARROW = false, bool TRAIN = false>
 __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
+    static_assert(!TRAIN || LSTM, "TRAIN: the fused LSTM step that also stores its gates");
     static_assert(!NARROW || (MI == 1 && !LSTM && !PP), "narrow tile: 128 x 64 only");
     constexpr int TBM = NARROW ? 128 * MI : (MI ? 64 * MI : 32);    // tile rows (MI = 0: the 32-row tile, one row tile per wave)
     constexpr int BN = NARROW ? 64 : MBN;               // tile columns
@@ -546,6 +547,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         // in ONE basic block (the asm pins the results ahead of the predicated stores; hipcc otherwise sinks each cell's ~190
         // instructions into its own store predicate, one serial dependency chain after the other)
         float cprev[TI][4], cnew[TI][4], hnew[TI][4];
+        float gsave[TRAIN ? TI : 1][4][4];
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -565,6 +567,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 cnew[ti][r] = __builtin_fmaf(fg, cprev[ti][r], ig * gg);
                 hnew[ti][r] = og * c_tanhf(cnew[ti][r]);
                 asm volatile("" : "+v"(cnew[ti][r]), "+v"(hnew[ti][r]));
+                if constexpr (TRAIN) { gsave[ti][r][0] = ig; gsave[ti][r][1] = fg; gsave[ti][r][2] = gg; gsave[ti][r][3] = og; }
             }
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
@@ -574,6 +577,10 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 if (valid && row < Mrows) {
                     g.lstm_c[row * H + unit] = cnew[ti][r];
                     g.lstm_h[row * g.lstm_ldh + unit] = hnew[ti][r];
+                    if constexpr (TRAIN) {
+                        float *g4 = g.lstm_gates + row * 4 * H + unit;
+                        g4[0] = gsave[ti][r][0]; g4[H] = gsave[ti][r][1]; g4[2 * H] = gsave[ti][r][2]; g4[3 * H] = gsave[ti][r][3];
+                    }
                 }
             }
         GSTAMP(2)
@@ -643,6 +650,21 @@ __global__ __launch_bounds__(256, MI <= 1 ? 3 : VFR_LSTM_WAVES) void lstm_step_m
 {
     const GemmArgs g = gp.p[blockIdx.z];      // private copy, see gemm_nt_mfma_pair
     gemm_nt_mfma_body<true, false, true, MI>(g);
+}
+template <int MI>
+__global__ __launch_bounds__(256, MI <= 1 ? 3 : 2) void lstm_step_train_mfma_pair(GemmPair gp)
+{
+    const GemmArgs g = gp.p[blockIdx.z];
+    gemm_nt_mfma_body<true, false, true, MI, false, false, true>(g);
+}
+// blockIdx.z = problem * nsplit + K range: 32-row tiles over one K range of one problem (gemm_nt_splitk_pair)
+__global__ __launch_bounds__(256, 3) void gemm_nt_mfma_splitk_pair(GemmPair gp, int nsplit, int64_t out_stride)
+{
+    const int z = blockIdx.z, d = z / nsplit, j = z - d * nsplit;
+    GemmArgs g = gp.p[d];
+    const int kc = g.K / nsplit;
+    g.A += (int64_t)j * kc; g.W += (int64_t)j * kc; g.out += (int64_t)j * out_stride; g.K = kc;
+    gemm_nt_mfma_body<true, false, false, 0>(g);
 }
 __global__ __launch_bounds__(512, 2) void lstm_step_mfma_pair_pp(GemmPair gp)
 {
@@ -726,7 +748,11 @@ int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
         const unsigned rt = (unsigned)cdiv(g0.M, rows);
         return xcd ? dim3(rt * (unsigned)cpx * 8u, 1, 2) : dim3(rt, (unsigned)ncol, 2);
     };
-    if (tile == 3) {                         // 32-row tiles, three workgroups per CU
+    if (g0.lstm_gates) {                     // training forward: the same step, gates stored as well (32- or 64-row tiles)
+        VFR_REQUIRE(g1.lstm_gates, VFR_EINVAL, "lstm_step_pair: gates buffer for one direction only");
+        if (tile == 3) hipLaunchKernelGGL(lstm_step_train_mfma_pair<0>, grid_for(32), dim3(256), 0, st, gp);
+        else           hipLaunchKernelGGL(lstm_step_train_mfma_pair<1>, grid_for(64), dim3(256), 0, st, gp);
+    } else if (tile == 3) {                  // 32-row tiles, three workgroups per CU
         hipLaunchKernelGGL(lstm_step_mfma_pair<0>, grid_for(32), dim3(256), 0, st, gp);
     } else if (tile != 2) {
         hipLaunchKernelGGL(lstm_step_mfma_pair<1>, grid_for(64), dim3(256), 0, st, gp);
@@ -764,6 +790,22 @@ int gemm_nt_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
     if (gemm_vec_ok(g0) && gemm_vec_ok(g1)) hipLaunchKernelGGL(gemm_nt_mfma_pair<true>, grid, dim3(256), 0, st, gp);
     else                                    hipLaunchKernelGGL(gemm_nt_mfma_pair<false>, grid, dim3(256), 0, st, gp);
     VFR_CHECK_LAUNCH("gemm_nt_mfma_pair");
+    return VFR_OK;
+}
+
+int gemm_nt_splitk_pair(const GemmArgs &g0, const GemmArgs &g1, int nsplit, int64_t out_stride, hipStream_t st)
+{
+    if (g0.M == 0 || g0.N == 0) return VFR_OK;
+    VFR_REQUIRE(g0.A && g0.W && g0.out && g1.A && g1.W && g1.out && g0.M == g1.M && g0.N == g1.N && g0.K == g1.K && nsplit >= 1 &&
+                    nsplit <= 16 && g0.epi == EPI_NONE && g1.epi == EPI_NONE && !g0.Cin && !g1.Cin, VFR_EINVAL,
+                "gemm_nt_splitk_pair: bad argument");
+    VFR_REQUIRE(g0.K % (4 * nsplit) == 0 && gemm_vec_ok(g0) && gemm_vec_ok(g1), VFR_EUNSUPPORTED,
+                "gemm_nt_splitk_pair: K must be a multiple of 4 * nsplit, operands 16-byte aligned with strides in whole float4");
+    ProfScope prof(g0.site, st);
+    GemmPair gp{{g0, g1}};
+    dim3 grid((unsigned)cdiv(g0.M, 32), (unsigned)cdiv(g0.N, MBN), (unsigned)(2 * nsplit));
+    hipLaunchKernelGGL(gemm_nt_mfma_splitk_pair, grid, dim3(256), 0, st, gp, nsplit, out_stride);
+    VFR_CHECK_LAUNCH("gemm_nt_mfma_splitk_pair");
     return VFR_OK;
 }
 

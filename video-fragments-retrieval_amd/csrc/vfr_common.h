@@ -109,6 +109,8 @@ struct GemmArgs {
     // accumulators start from P[lstm_tok[m]] (the clamped token of row m's query at this step) -- the same chain,
     // continued over h.
     const int *lstm_tok;
+    // training forward (nullable): the activated gates i, f, g, o of every row, [M, 4H] -- what the backward needs
+    float *lstm_gates;
 };
 int gemm_nt(const GemmArgs &g, hipStream_t st);
 // two GEMMs of identical shape as ONE grid (blockIdx.z picks the problem): fills the chip when one alone leaves a
@@ -116,6 +118,10 @@ int gemm_nt(const GemmArgs &g, hipStream_t st);
 int gemm_nt_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st);
 // fused LSTM step for both directions (see GemmArgs::lstm_H)
 int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st);
+// two GEMMs of identical shape, each cut into nsplit equal K ranges, as ONE grid of 32-row tiles: range j of problem d writes
+// its partial chains to out_d + j * out_stride (the consumer adds the partials in the order 0..nsplit-1).  For the skinny
+// products of backpropagation through time (dh = dpre W_hh: [B,4H] x [4H,H], B a few hundred) whose own grid is 64 workgroups.
+int gemm_nt_splitk_pair(const GemmArgs &g0, const GemmArgs &g1, int nsplit, int64_t out_stride, hipStream_t st);
 // W_ih [4H, E] -> [128*ceil(H/32), E] in the fused step's tile-column order (for the vocabulary input-projection table)
 int lstm_permute_rows(const float *W, int H, int E, float *out, hipStream_t st);
 // copy a [rows, cols] block out of a wider row-major matrix into a dense, 16-byte aligned buffer

@@ -8,8 +8,10 @@ of the kernels in ``csrc/train.hip``:
 * ``linear(x, W, b)``                       -- ``nn.Linear`` (``lang_fc``, the BERT projection): dX = dY W, dW = dY^T X, db = colsum dY
 * ``visual_mlp(x, W1, b1, W2, b2)``         -- ``visual_fc[0..2]``: Linear / ReLU / Linear with the hidden layer saved
 * ``bilstm_final(x, lstm weights, H)``      -- ``nn.LSTM(bidirectional)`` over the embedded words, returning h_n [B, 2H]:
-  per step one GEMM ``h W_hh^T`` + the cell kernel (gates and cell states of all T steps kept), backward = T steps of
-  (cell backward kernel, ``dh = dpre W_hh``) and then ONE GEMM per weight over all steps, dW = DP^T [h | x].
+  forward = T launches of the inference path's fused step for both directions (``[x_t | h] [W_ih | W_hh]^T`` + cell in one
+  kernel, here also keeping the gates and the states of all T steps); backward = T x (one cell-backward launch, one
+  split-K GEMM grid ``dh = dpre W_hh``, both directions each) and then ONE GEMM per weight over all steps,
+  dW = DP^T [h | x].  E or H not a multiple of 4: the same recurrence step by step from Python (unfused kernels).
 
 ``dX = dY W`` is ``linear(dY, W^T)``; ``dW = dY^T X`` is ``linear(dY^T, X^T)`` (the GEMM contracts the trailing dimension of
 both operands), hence the transposes.  The dropout after ``visual_fc[2]`` stays ``torch.nn.functional.dropout`` (its mask
@@ -81,6 +83,12 @@ class _BiLSTMFn(torch.autograd.Function):
         H = ws[1].shape[1]
         dev = x.device
         x2 = x.contiguous().reshape(B * T, E)
+        ctx.dims = (B, T, E, H)
+        ctx.fused = E % 4 == 0 and H % 4 == 0
+        if ctx.fused:
+            gates, cs, hs = _vfr.bilstm_train_forward(x2.reshape(B, T, E), [w.contiguous() for w in ws])
+            ctx.save_for_backward(x2, *ws, gates, cs, hs)
+            return torch.cat([hs[0, T], hs[1, T]], dim=1)
         saved = []
         out = torch.empty((B, 2 * H), dtype=torch.float32, device=dev)
         for d in range(2):
@@ -96,7 +104,6 @@ class _BiLSTMFn(torch.autograd.Function):
             out[:, d * H:(d + 1) * H] = hs[T]
             saved += [gates, cs, hs]
         ctx.save_for_backward(x2, *ws, *saved)
-        ctx.dims = (B, T, E, H)
         return out
 
     @staticmethod
@@ -110,18 +117,24 @@ class _BiLSTMFn(torch.autograd.Function):
         gx = torch.zeros((B, T, E), dtype=torch.float32, device=dev) if need_x else None
         grads = []
         x_tm = x2.reshape(B, T, E).transpose(0, 1).contiguous()              # [T, B, E] time-major
+        W_hhT = [_vfr.transpose(ws[1].contiguous()), _vfr.transpose(ws[5].contiguous())]     # [H, 4H]
+        if ctx.fused:
+            gates2, cs2, hs2 = saved
+            DP2 = _vfr.bilstm_train_backward(gout, gates2, cs2, W_hhT[0], W_hhT[1])
         for d in range(2):
-            W_ih, W_hh = ws[4 * d], ws[4 * d + 1]
-            gates, cs, hs = saved[3 * d:3 * d + 3]
-            W_hhT = _vfr.transpose(W_hh)                                     # [H, 4H]
+            W_ih = ws[4 * d]
             W_ihT = _vfr.transpose(W_ih) if need_x else None                # [E, 4H]
-            dh = gout[:, d * H:(d + 1) * H].contiguous()
-            dc = torch.zeros((B, H), dtype=torch.float32, device=dev)
-            DP = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
-            for s in range(T - 1, -1, -1):
-                _vfr.lstm_cell_backward(dh, dc, gates[s], cs[s], cs[s + 1], DP[s])
-                if s > 0:
-                    dh = _lin(DP[s], W_hhT)                                  # gradient reaching h of step s - 1
+            if ctx.fused:
+                hs, DP = hs2[d], DP2[d]
+            else:
+                gates, cs, hs = saved[3 * d:3 * d + 3]
+                dh = gout[:, d * H:(d + 1) * H].contiguous()
+                dc = torch.zeros((B, H), dtype=torch.float32, device=dev)
+                DP = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
+                for s in range(T - 1, -1, -1):
+                    _vfr.lstm_cell_backward(dh, dc, gates[s], cs[s], cs[s + 1], DP[s])
+                    if s > 0:
+                        dh = _lin(DP[s], W_hhT[d])                           # gradient reaching h of step s - 1
             DPf = DP.reshape(T * B, 4 * H)
             DPT = _vfr.transpose(DPf)                                        # [4H, T*B]
             # inputs in STEP order: step s of the reverse direction read time T-1-s
