@@ -154,11 +154,15 @@ int vfr_topk_merge_f32(const float *part_dist, const int64_t *part_idx, int G, i
  * VFR_KEY_EMPTY = (+inf, 0xffffffff) marks an unused slot.  pack: (dist, idx) [n] -> keys [n]
  * (idx < 0 -> empty).  merge: part_keys [G, Nq, k] -> out_dist/out_idx [Nq, k] (both or neither)
  * and/or out_keys [Nq, k] (nullable) -- the merged list as keys, whose column k-1 is the
- * threshold seed of the next pass and which can be merged again without repacking.             */
+ * threshold seed of the next pass and which can be merged again without repacking.  _strided: slot
+ * g starts at part_keys + g * slot_stride (>= Nq * k int64 elements) -- the lists as they lie inside
+ * the rows of a packed exchange buffer, merged in place.                                          */
 #define VFR_KEY_EMPTY 0x7F800000FFFFFFFFll
 int vfr_topk_pack_keys(const float *dist, const int64_t *idx, int64_t n, int64_t *keys, vfr_stream_t stream);
 int vfr_topk_merge_keys(const int64_t *part_keys, int G, int64_t Nq, int k, float *out_dist, int64_t *out_idx,
                         int64_t *out_keys, vfr_stream_t stream);
+int vfr_topk_merge_keys_strided(const int64_t *part_keys, int64_t slot_stride, int G, int64_t Nq, int k, float *out_dist,
+                                int64_t *out_idx, int64_t *out_keys, vfr_stream_t stream);
 /* a12  position of the first ground-truth-positive moment (model/evaluate.py:67-77,
  * np.where(labels[order])[0][0]) needs that moment's key: keys[r, sel[s]] = min over m < M with
  * labels[r, s, m] != 0 of (own_scores[s, m], id_base[s] + m); every other entry of keys [R, Nq]

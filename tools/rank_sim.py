@@ -23,32 +23,38 @@ dev = torch.device("cuda:0")
 
 
 class FakeDist:
+    """Stand-in collectives without wire time AND without host work the real ones do not have: a gather is one broadcast
+    copy of the own row into the N slots; the best-GT keys of queries owned by other ranks (KEY_INF here, finite after the
+    real MIN over ranks) are replaced by a typical key computed ONCE, with a single elementwise kernel per call."""
     class ReduceOp:
         SUM, MIN, MAX = "sum", "min", "max"
     calls = 0
+    typical = None
 
-    def all_gather(self, parts, t):
+    @classmethod
+    def patch(cls, gtk):
+        if cls.typical is None:
+            cls.typical = gtk[gtk != engine.KEY_INF].median().clone()
+        torch.where(gtk == engine.KEY_INF, cls.typical, gtk, out=gtk)
+
+    def all_gather_into_tensor(self, out, t):
         FakeDist.calls += 1
         if t.dim() == 1 and t.numel() == Nq * k + 2 * Nq:
-            # first exchange of sharded_search_fused: [sample keys | best-GT keys]; queries owned by other ranks get a typical key
-            gtk = t[Nq * k:]
-            inf = gtk == engine.KEY_INF
-            if bool(inf.any()):
-                gtk[inf] = gtk[~inf].median()
-        for p in parts:
-            p.copy_(t)
+            if FakeDist.rows % 2 == 0:             # first exchange of sharded_search_fused: [sample keys | best-GT keys]
+                self.patch(t[Nq * k:])
+            FakeDist.rows += 1
+        out.view(N, -1).copy_(t.reshape(1, -1).expand(N, -1))
 
     def all_reduce(self, t, op=None):
         FakeDist.calls += 1
-        if op == "min" and t.dtype == torch.int64:          # best-GT keys: queries owned by other ranks get a typical key
-            inf = t == engine.KEY_INF
-            if bool(inf.any()):
-                t[inf] = t[~inf].median()
+        if op == "min" and t.dtype == torch.int64:
+            self.patch(t)
 
     def barrier(self):
         pass
 
 
+FakeDist.rows = 0
 engine._dist = lambda: FakeDist()
 counts_all = synth.clip_counts(Nv_all, n, seed=123)
 off_all = np.concatenate([[0], np.cumsum(counts_all.astype(np.int64))])

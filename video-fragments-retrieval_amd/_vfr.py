@@ -49,6 +49,7 @@ SIGNATURES = {
     "vfr_topk_merge_f32": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "vfr_topk_pack_keys": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "vfr_topk_merge_keys": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "vfr_topk_merge_keys_strided": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "vfr_gt_best_keys_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "vfr_gt_labels_u8": (_i32, [_vp, _vp, _vp, _i64, _i32, ctypes.POINTER(ctypes.c_double), _i32, _i32, _i32, _vp, _vp]),
     "vfr_ranking_loss_workspace_bytes": (_sz, [_i64, _i64, _i32]),
@@ -380,13 +381,17 @@ def topk_pack_keys(dist: torch.Tensor, idx: torch.Tensor, out: torch.Tensor | No
 
 
 def topk_merge_keys(part_keys: torch.Tensor, want_lists: bool = True, want_keys: bool = False):
-    """[G,Nq,k] int64 key lists -> (dist [Nq,k] | None, idx [Nq,k] | None, keys [Nq,k] | None)."""
-    pk = _dev(part_keys, torch.int64, "part_keys")
+    """[G,Nq,k] int64 key lists -> (dist [Nq,k] | None, idx [Nq,k] | None, keys [Nq,k] | None).  The slots may be views into
+    wider rows (each [Nq,k] dense, any slot stride >= Nq*k): the lists inside a packed exchange buffer are merged in place."""
+    pk = part_keys
     G, Nq, k = pk.shape
+    if not (pk.is_cuda and pk.dtype == torch.int64 and pk.stride(2) == 1 and pk.stride(1) == k and pk.stride(0) >= Nq * k):
+        pk = _dev(part_keys, torch.int64, "part_keys")
     od = torch.empty((Nq, k), dtype=torch.float32, device=pk.device) if want_lists else None
     oi = torch.empty((Nq, k), dtype=torch.int64, device=pk.device) if want_lists else None
     ok = torch.empty((Nq, k), dtype=torch.int64, device=pk.device) if want_keys else None
-    _check(lib().vfr_topk_merge_keys(pk.data_ptr(), G, Nq, k, _ptr(od), _ptr(oi), _ptr(ok), _stream()), "vfr_topk_merge_keys")
+    _check(lib().vfr_topk_merge_keys_strided(pk.data_ptr(), pk.stride(0) if G > 1 else Nq * k, G, Nq, k, _ptr(od), _ptr(oi), _ptr(ok),
+                                             _stream()), "vfr_topk_merge_keys")
     return od, oi, ok
 
 

@@ -871,8 +871,8 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
 // appended only if it beats the running k-th key -- after the first round almost nothing is, so a query costs ~2 sorts.
 template <int KPL, bool PACKED>
 __global__ __launch_bounds__(256) void topk_merge_parts_kernel(const float *__restrict__ pd,
-                                                               const int64_t *__restrict__ pi, int G, int64_t Nq,
-                                                               int k, float *__restrict__ out_dist,
+                                                               const int64_t *__restrict__ pi, int64_t slot_stride, int G,
+                                                               int64_t Nq, int k, float *__restrict__ out_dist,
                                                                int64_t *__restrict__ out_idx,
                                                                int64_t *__restrict__ out_keys)
 {
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void topk_merge_parts_kernel(const float *__re
             x[i] = KEY_MAX;
             if (gi < total) {
                 const int g = gi / k, off = gi - g * k;
-                const int64_t at = ((int64_t)g * Nq + q) * k + off;
+                const int64_t at = (int64_t)g * slot_stride + q * k + off;        // slot_stride >= Nq * k elements
                 if constexpr (PACKED) {
                     const unsigned long long v = (unsigned long long)pi[at];
                     x[i] = v >= KEY_EMPTY ? KEY_MAX : v;
@@ -1600,13 +1600,14 @@ int vfr_score_topk_mfma_stats(const void *workspace, int64_t Nq, int Nv, int tot
 }
 
 static int launch_merge_parts(const float *pd, const int64_t *pi, bool packed, int G, int64_t Nq, int k, float *od,
-                              int64_t *oi, int64_t *okeys, vfr_stream_t stream)
+                              int64_t *oi, int64_t *okeys, vfr_stream_t stream, int64_t slot_stride = 0)
 {
+    if (slot_stride == 0) slot_stride = Nq * k;
     dim3 grid((unsigned)vfr::cdiv(Nq, 4)), block(256);
     const int kpl = vfr::kpl_for(k);
     vfr::ProfScope prof(vfr::SITE_EXCHANGE, vfr::as_stream(stream));
 #define VFR_MERGE(KPL, PACKED) hipLaunchKernelGGL((vfr::topk_merge_parts_kernel<KPL, PACKED>), grid, block, 0, \
-                                                  vfr::as_stream(stream), pd, pi, G, Nq, k, od, oi, okeys)
+                                                  vfr::as_stream(stream), pd, pi, slot_stride, G, Nq, k, od, oi, okeys)
     if (packed) { if (kpl == 4) VFR_MERGE(4, true); else VFR_MERGE(8, true); }
     else        { if (kpl == 4) VFR_MERGE(4, false); else VFR_MERGE(8, false); }
 #undef VFR_MERGE
@@ -1636,15 +1637,22 @@ int vfr_topk_pack_keys(const float *dist, const int64_t *idx, int64_t n, int64_t
     return VFR_OK;
 }
 
-int vfr_topk_merge_keys(const int64_t *part_keys, int G, int64_t Nq, int k, float *out_dist, int64_t *out_idx,
-                        int64_t *out_keys, vfr_stream_t stream)
+int vfr_topk_merge_keys_strided(const int64_t *part_keys, int64_t slot_stride, int G, int64_t Nq, int k, float *out_dist,
+                                int64_t *out_idx, int64_t *out_keys, vfr_stream_t stream)
 {
     VFR_REQUIRE(part_keys && G > 0 && Nq >= 0 && k > 0 && ((out_dist && out_idx) || out_keys) &&
-                (out_dist == nullptr) == (out_idx == nullptr), VFR_EINVAL, "vfr_topk_merge_keys: bad argument");
+                (out_dist == nullptr) == (out_idx == nullptr) && slot_stride >= Nq * k, VFR_EINVAL,
+                "vfr_topk_merge_keys: bad argument");
     VFR_REQUIRE(k <= 448, VFR_EUNSUPPORTED, "vfr_topk_merge_keys: k=%d > 448", k);
     VFR_REQUIRE((int64_t)G * k < (1ll << 31), VFR_EUNSUPPORTED, "vfr_topk_merge_keys: G*k too large");
     if (Nq == 0) return VFR_OK;
-    return launch_merge_parts(nullptr, part_keys, true, G, Nq, k, out_dist, out_idx, out_keys, stream);
+    return launch_merge_parts(nullptr, part_keys, true, G, Nq, k, out_dist, out_idx, out_keys, stream, slot_stride);
+}
+
+int vfr_topk_merge_keys(const int64_t *part_keys, int G, int64_t Nq, int k, float *out_dist, int64_t *out_idx,
+                        int64_t *out_keys, vfr_stream_t stream)
+{
+    return vfr_topk_merge_keys_strided(part_keys, Nq * k, G, Nq, k, out_dist, out_idx, out_keys, stream);
 }
 
 int vfr_gt_best_keys_f32(const float *own_scores, int64_t n_sel, int M, int score_stride, const uint8_t *labels, int R,

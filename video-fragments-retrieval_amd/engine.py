@@ -495,8 +495,11 @@ def sharded_search_fused(shard: CorpusShard, Q, k, keys_local, ops, world, works
         exchange 2  all_gather of [Nq x k final keys | 2 x Nq rank counts] per rank -> the merged top-k and, by a SUM over the
                     ranks, the global rank counts.
 
-    The sample pass therefore runs without rank keys; the sample videos get a rank-only pass (k = 0) once the global keys
-    are known.  Everything stays int64 (keys and counts), so both folds are exact.  Returns (dist, idx, counts)."""
+    The sample pass (the rank's first 256/world videos, no rank keys yet) only produces the seed; the main pass then covers
+    the WHOLE shard, sample videos included (2-3 % more scorings than skipping them, but no separate rank-only pass over the
+    sample, no sub-bank and one list fewer in the final merge).  The seed handed on is the sample's k-th key + 1: the kernel
+    collects keys strictly below its seed, and the k-th sample moment itself must stay collectable.  Everything stays int64
+    (keys and counts), so both folds are exact.  Returns (dist, idx, counts)."""
     dist = _dist()
     Nq = Q.shape[0]
     nloc = shard.hi - shard.lo
@@ -513,24 +516,16 @@ def sharded_search_fused(shard: CorpusShard, Q, k, keys_local, ops, world, works
     keys = buf[:, Nq * k:].min(dim=0).values.view(2, Nq)                             # global best-GT keys (KEY_INF: none)
     if on_keys is not None:
         on_keys(keys)
-    lists = torch.empty((world + 1, Nq, k), dtype=torch.int64, device=d_a.device)    # slot `world`: the global sample list
-    lists[:world].copy_(buf[:, :Nq * k].view(world, Nq, k))
-    _, _, s_k = ops.merge_keys(lists[:world], want_lists=False, want_keys=True)
-    lists[world].copy_(s_k)
-    seed = s_k[:, k - 1].contiguous()
+    lists = buf[:, :Nq * k].view(world, Nq, k)                                       # strided view: merge_keys takes slot strides
+    _, _, s_k = ops.merge_keys(lists, want_lists=False, want_keys=True)
+    seed = (s_k[:, k - 1] + 1).clamp_(max=KEY_INF)
     rank_dist, rank_idx = _unpack_key(keys)
-    rank_dist, rank_idx = rank_dist.contiguous(), rank_idx.contiguous()
-    _, _, cnt = ops.score_topk(Q, bank_a, 0, rank_dist, rank_idx, workspace=workspace)         # the sample videos' counts
-    if s_r < nloc:
-        bank_b = ops.slice_bank(shard.bank, counts_loc, s_r, nloc)
-        d_b, i_b, cnt = ops.score_topk(Q, bank_b, k, rank_dist, rank_idx, workspace=workspace, count_lt=cnt, thr_seed=seed)
-        ops.pack_keys(d_b, i_b, out=mine[:Nq * k].view(Nq, k))
-    else:
-        mine[:Nq * k].fill_(KEY_INF)
+    d_b, i_b, cnt = ops.score_topk(Q, shard.bank, k, rank_dist.contiguous(), rank_idx.contiguous(), workspace=workspace,
+                                   thr_seed=seed)
+    ops.pack_keys(d_b, i_b, out=mine[:Nq * k].view(Nq, k))
     mine[Nq * k:].copy_(cnt.reshape(-1))
     _all_gather_rows(dist, buf, mine)
     counts = buf[:, Nq * k:].sum(dim=0).view(2, Nq)
-    lists[:world].copy_(buf[:, :Nq * k].view(world, Nq, k))
     od, oi, _ = ops.merge_keys(lists)
     return od, oi, counts
 
