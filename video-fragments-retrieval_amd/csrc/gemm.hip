@@ -160,16 +160,22 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     constexpr int BN = NARROW ? 64 : MBN;               // tile columns
     constexpr int NA = TBM / 32, NW = BN / 32;          // float4 staging loads per thread of A / of W
     // LDS row layout.  128-row tiles: 32 floats + 4 of padding (row stride 36: the 16 rows x 4 k's of a fragment read fall in
-    // 64 distinct banks).  Smaller tiles: NO padding, the eight 16-byte chunks of row r stored at chunk ^ ((r >> 1) & 7)
-    // instead -- equally conflict-free (bank = 32*(r&1) + 4*((k4 ^ (r>>1)) & 7) + q), and the 192-row double buffer is
-    // 48 KB instead of 54 KB, so THREE workgroups fit the CU's 160 KB where the padded layout stopped at two by 2 KB.
-    constexpr bool SWZ = MI <= 1 && !PP;
-    constexpr int MLD = SWZ ? 32 : MLD_PAD;
-    // double-buffered tiles: [2][A TBMx36 | W 128x36] floats (73,728 B at MI = 2) -> two workgroups per CU
+    // 64 distinct banks).  Smaller tiles: blocks of 16 rows, row r of a block at 32*r + 4*(r >> 1) floats, block stride 544 =
+    // 34 per row -- equally conflict-free (bank = 32*(r&1) + 4*(r>>1) + 4*k4 + q), LINEAR in the k-slice (every fragment read
+    // of a K-tile is base + immediate; an XOR swizzle of the 16-byte chunks, the first version, cost three address VALU ops
+    // per slice, and VALU time is matrix-pipe time on gfx950: tools/ubench/coissue.hip), every float4 16-byte aligned, and
+    // the 192-row double buffer is 51 KB instead of 54 KB, so THREE workgroups fit the CU's 160 KB.
+    constexpr bool SKEW = MI <= 1 && !PP;
+    constexpr int RBLK = SKEW ? 544 : 16 * MLD_PAD;             // floats per block of 16 rows
+    constexpr int A_FLOATS = (TBM / 16) * RBLK, BUF_FLOATS = ((TBM + BN) / 16) * RBLK;
+    auto lds_off = [](int row, int k) {                         // float offset of (row, k) inside a tile
+        return SKEW ? (row >> 4) * 544 + (row & 15) * 32 + 4 * ((row & 15) >> 1) + k : row * MLD_PAD + k;
+    };
+    // double-buffered tiles: [2][A | W] -> two (padded 128-row tiles) or three workgroups per CU
     constexpr int NBUF = PP ? 1 : (LSTM ? VFR_LSTM_NBUF : VFR_GEMM_NBUF);
-    __shared__ __attribute__((aligned(16))) float lds_all[(PP ? 2 : 1) * NBUF * (TBM + BN) * MLD];
+    __shared__ __attribute__((aligned(16))) float lds_all[(PP ? 2 : 1) * NBUF * BUF_FLOATS];
     const int grp = PP ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // tile group of this wave
-    float *lds = lds_all + grp * NBUF * (TBM + BN) * MLD;
+    float *lds = lds_all + grp * NBUF * BUF_FLOATS;
     const int tid = PP ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = NARROW ? wave : wave >> 1, wn = NARROW ? 0 : wave & 1;
     int64_t m0 = (int64_t)(PP ? blockIdx.x * 2 + grp : blockIdx.x) * TBM;
@@ -206,7 +212,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // accumulators: the wave's 16*TI x 64 outputs as TI x 4 tiles of v_mfma_f32_16x16x4_f32 (4 registers each); lane l holds
     // rows 4*(l>>4) + r (r = 0..3) and column l & 15 of a tile
     constexpr int TI = MI ? 2 * MI : 1;
-    const int l15 = lane & 15, lq = lane >> 4, fsw = (l15 >> 1) & 7;
+    const int l15 = lane & 15, lq = lane >> 4;
     f32x4 acc[TI][4];
     auto init_acc = [&]() {
         if (LSTM && g.lstm_tok) {
@@ -243,15 +249,22 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 
     float4 ra[NA], rw[NW];
     // Zero-fill of staged elements outside the operand (conv padding taps, the tail of a segmented K) is decided when the
-    // load is ISSUED but applied when the registers are written to LDS: a select right after the load would make hipcc
-    // wait for the load (vmcnt(0)) before the MFMA block and expose its latency in every K-tile.
-    bool za[NA], zw = false;
+    // load is ISSUED but applied (to the A side only) when the registers are written to LDS: a select right after the load
+    // would make hipcc wait for the load (vmcnt(0)) before the MFMA block and expose its latency in every K-tile.
+    bool za[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) za[i] = false;
     // Staging loads.  Full K-tiles use UNCONDITIONAL loads (row index clamped into range; rows past M / N are
     // never stored) so the compiler can leave them in flight across the MFMA block -- a per-load bounds branch
     // makes hipcc drain vmcnt(0) right after issuing them.  Only the last, partial K-tile takes the guarded form.
-    const float *arow[NA], *wrow[NW], *arow2[NA], *wrow2[NW];
+    const float *arow[NA], *wrow[NW];
+    // Fused LSTM step: the staged rows are addressed as UNIFORM base (segment pointer + the tile's k, scalar registers) +
+    // a per-thread 32-bit byte offset that never changes (row * ld + the thread's k within a tile), so a K-tile costs one
+    // select per load and no 64-bit vector arithmetic (lstm_step_pair checks that the offsets fit 32 bits).  A segment
+    // shorter than one K-tile has a single tile whose out-of-range lanes re-read k = 0 (zeroed on the A side).
+    unsigned aoff1[NA], aoff2[NA], woff1[NW], woff2[NW];
+    const int kkl = (tid & 7) * 4;
+    const int kk1 = (LSTM && g.K < MBK && kkl >= g.K) ? 0 : kkl, kk2 = (LSTM && g.K2 < MBK && kkl >= g.K2) ? 0 : kkl;
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
         const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
@@ -261,7 +274,8 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             int unit = by * 32 + (row >> 6) * 16 + (row & 15);
             unit = unit < g.lstm_H ? unit : g.lstm_H - 1;
             nw = (int64_t)gate * g.lstm_H + unit;
-            wrow2[i] = g.W2 + nw * g.ldw2 + kk;
+            woff1[i] = (unsigned)((nw * g.ldw + kk1) * 4);
+            woff2[i] = (unsigned)((nw * g.ldw2 + kk2) * 4);
         }
         wrow[i] = g.W + nw * g.ldw + kk;
     }
@@ -271,9 +285,10 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         const int64_t ma = m0 + row < Mrows ? m0 + row : Mrows - 1;
         if (LSTM) {
             const int64_t hsrc = ma >= Mprev ? 0 : ma;             // a row joining now continues from the pad row's state
-            arow2[i] = g.A2 + hsrc * g.lda2 + kk;
+            aoff2[i] = (unsigned)((hsrc * g.lda2 + kk2) * 4);
+            aoff1[i] = (unsigned)(((g.lstm_xrow ? (int64_t)g.lstm_xrow[ma] : ma) * g.lda + kk1) * 4);
         }
-        arow[i] = CONV ? g.A : g.A + ((LSTM && g.lstm_xrow) ? (int64_t)g.lstm_xrow[ma] : ma) * g.lda + kk;
+        arow[i] = CONV ? g.A : g.A + ma * g.lda + kk;
     }
     auto gload_full = [&](int k0) {
 #pragma unroll
@@ -332,34 +347,34 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) rw[i] = *reinterpret_cast<const float4 *>(wrow[i] - kk + kc);    // row clamped, k clamped
-        zw = !kok;
     };
-    // ---- segmented-K loader (LSTM step): tiles [0, nk1) walk [A | W] over K, tiles [nk1, nk1+nk2) walk [A2 | W2]
-    // over K2; a partial tile is zero-selected after an unconditional clamped load (fma(0,0,acc) == acc).
+    // ---- segmented-K loader (LSTM step): tiles [0, nk1) walk [A | W] over K, tiles [nk1, nk1+nk2) walk [A2 | W2] over K2.
+    // A partial last tile of a segment is shifted BACK to end exactly at the segment's end (nothing is read past a row);
+    // its lanes below the previous tile's end are zeroed on the A side when the registers go to LDS (fma(0, w, acc) == acc for
+    // the finite w re-read beside them), and so are the lanes past the end of a segment shorter than one tile.
     const int nk1 = (g.K + MBK - 1) / MBK;
+    bool zq = false;
     auto gload_seg = [&](int k0t) {
         const int kt = k0t / MBK;
         const bool second = kt >= nk1;
-        const int kk = (tid & 7) * 4, k = (second ? kt - nk1 : kt) * MBK + kk;
-        const bool kok = k < (second ? g.K2 : g.K);
-        const int kc = kok ? k : 0;
+        const int Kseg = second ? g.K2 : g.K, kseg = (second ? kt - nk1 : kt) * MBK;
+        const int kb = (kseg + MBK > Kseg && Kseg >= MBK) ? Kseg - MBK : kseg;
+        const int zlo = kseg - kb, zhi = Kseg < MBK ? Kseg : MBK;
+        zq = kkl < zlo || kkl >= zhi;
+        const char *ba = reinterpret_cast<const char *>((second ? g.A2 : g.A) + kb);
+        const char *bw = reinterpret_cast<const char *>((second ? g.W2 : g.W) + kb);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const float *ap = (second ? arow2[i] : arow[i]) - kk + kc;
-            ra[i] = *reinterpret_cast<const float4 *>(ap);
-            za[i] = !kok;
+            ra[i] = *reinterpret_cast<const float4 *>(ba + (second ? aoff2[i] : aoff1[i]));
+            za[i] = zq;
         }
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const float *wp = (second ? wrow2[i] : wrow[i]) - kk + kc;
-            rw[i] = *reinterpret_cast<const float4 *>(wp);
-        }
-        zw = !kok;
+        for (int i = 0; i < NW; ++i) rw[i] = *reinterpret_cast<const float4 *>(bw + (second ? woff2[i] : woff1[i]));
     };
     const int nk_full = LSTM ? nk1 + (g.K2 + MBK - 1) / MBK
                              : CONV ? (g.K + MBK - 1) / MBK : g.K / MBK;     // conv / lstm: every tile through a select loader
     auto swrite = [&](int b) {
-        float *As = lds + b * (TBM + BN) * MLD, *Ws = As + TBM * MLD;
+        float *As = lds + b * BUF_FLOATS, *Ws = As + A_FLOATS;
 #ifdef VFR_GEMM_NOSWRITE      /* TIMING EXPERIMENT ONLY (wrong results): staged registers are consumed but never written to LDS */
 #pragma unroll
         for (int i = 0; i < NA; ++i) asm volatile("" :: "v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w));
@@ -372,23 +387,24 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
             float4 v = ra[i];
             if (CONV || LSTM) { const bool z = za[i]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
-            *reinterpret_cast<float4 *>(&As[row * MLD + (SWZ ? (((f & 7) ^ ((row >> 1) & 7)) << 2) : kk)]) = v;
+            *reinterpret_cast<float4 *>(&As[lds_off(row, kk)]) = v;
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
             float4 v = rw[i];
-            if (CONV || LSTM) { v.x = zw ? 0.f : v.x; v.y = zw ? 0.f : v.y; v.z = zw ? 0.f : v.z; v.w = zw ? 0.f : v.w; }
-            *reinterpret_cast<float4 *>(&Ws[row * MLD + (SWZ ? (((f & 7) ^ ((row >> 1) & 7)) << 2) : kk)]) = v;
+            // (W is not zero-filled: wherever a k lies outside the operand the A side is zero, and the weight re-read from a
+            // clamped address beside it is finite, so the product leaves the chain as it is)
+            *reinterpret_cast<float4 *>(&Ws[lds_off(row, kk)]) = v;
         }
     };
     auto compute = [&](int b) {
-        const float *As = lds + b * (TBM + BN) * MLD, *Ws = As + TBM * MLD;
+        const float *As = lds + b * BUF_FLOATS, *Ws = As + A_FLOATS;
         // fragment of tile row block ti at k-slice k4: ONE dword per lane, A[16*ti + (lane & 15)][4*k4 + (lane >> 4)] -- exactly
-        // the 16x16x4 operand layout, read with ds_read_b32 (bank = 36*r + q mod 64: 64 distinct banks, conflict-free)
-        const float *ap = &As[(wm * (16 * TI) + l15) * MLD + lq];
-        const float *wp = &Ws[(wn * 64 + l15) * MLD + lq];
-        auto kcol = [&](int k4) { return SWZ ? ((k4 ^ fsw) << 2) : k4 * 4; };   // every fragment row has (row >> 1) & 7 == fsw
+        // the 16x16x4 operand layout, read with ds_read_b32 (64 distinct banks, conflict-free, in both layouts)
+        const float *ap = &As[lds_off(wm * (16 * TI) + l15, lq)];
+        const float *wp = &Ws[lds_off(wn * 64 + l15, lq)];
+        auto kcol = [&](int k4) { return k4 * 4; };
         // fragment ring: the reads of slice k4+DEPTH are issued (and pinned) BEFORE the MFMAs of slice k4, so their
         // latency hides under the matrix pipe.  DEPTH 2 matters when a workgroup is ALONE on its CU (partial last round, small
         // launches): with one slice of cover a lone wave's stream stalled on LDS latency and a half-filled round cost as much
@@ -398,18 +414,18 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
-            for (int ti = 0; ti < TI; ++ti) fa[d][ti] = ap[ti * 16 * MLD + kcol(d)];
+            for (int ti = 0; ti < TI; ++ti) fa[d][ti] = ap[ti * RBLK + kcol(d)];
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj) fb[d][tj] = wp[tj * 16 * MLD + kcol(d)];
+            for (int tj = 0; tj < 4; ++tj) fb[d][tj] = wp[tj * RBLK + kcol(d)];
         }
 #pragma unroll
         for (int k4 = 0; k4 < MBK / 4; ++k4) {
             const int cur = k4 % RING, nxt = (k4 + DEPTH) % RING;
             if (k4 + DEPTH < MBK / 4) {
 #pragma unroll
-                for (int ti = 0; ti < TI; ++ti) fa[nxt][ti] = ap[ti * 16 * MLD + kcol(k4 + DEPTH)];
+                for (int ti = 0; ti < TI; ++ti) fa[nxt][ti] = ap[ti * RBLK + kcol(k4 + DEPTH)];
 #pragma unroll
-                for (int tj = 0; tj < 4; ++tj) fb[nxt][tj] = wp[tj * 16 * MLD + kcol(k4 + DEPTH)];
+                for (int tj = 0; tj < 4; ++tj) fb[nxt][tj] = wp[tj * RBLK + kcol(k4 + DEPTH)];
             }
             __builtin_amdgcn_sched_barrier(0);
             // one MFMA = k, k+1, k+2, k+3 in order on top of the accumulator: the oracle's chain
@@ -456,14 +472,13 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         const int nk = nk_full;
         float fa[RING][TI], fb[RING][4];
         auto frag_read = [&](int buf, int slice, int slot) {
-            const float *As = lds + buf * (TBM + BN) * MLD, *Ws = As + TBM * MLD;
-            const int kc = SWZ ? ((slice ^ fsw) << 2) : slice * 4;
-            const float *ap = &As[(wm * (16 * TI) + l15) * MLD + lq + kc];
-            const float *wp = &Ws[(wn * 64 + l15) * MLD + lq + kc];
+            const float *As = lds + buf * BUF_FLOATS, *Ws = As + A_FLOATS;
+            const float *ap = &As[lds_off(wm * (16 * TI) + l15, lq) + slice * 4];
+            const float *wp = &Ws[lds_off(wn * 64 + l15, lq) + slice * 4];
 #pragma unroll
-            for (int ti = 0; ti < TI; ++ti) fa[slot][ti] = ap[ti * 16 * MLD];
+            for (int ti = 0; ti < TI; ++ti) fa[slot][ti] = ap[ti * RBLK];
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj) fb[slot][tj] = wp[tj * 16 * MLD];
+            for (int tj = 0; tj < 4; ++tj) fb[slot][tj] = wp[tj * RBLK];
         };
         // the first K-tile's loads are in flight while the accumulators are initialised (C-in / the LSTM table gather: two
         // dependent load rounds whose latency would otherwise stand alone at the head of every tile)
@@ -731,6 +746,10 @@ int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
         VFR_REQUIRE(((g->lda | g->ldw | g->lda2 | g->ldw2 | g->K | g->K2) & 3) == 0 &&
                         ((((uintptr_t)g->A) | ((uintptr_t)g->W) | ((uintptr_t)g->A2) | ((uintptr_t)g->W2)) & 15) == 0,
                     VFR_EUNSUPPORTED, "lstm_step_pair: E, H and the operand strides must be multiples of 4 floats, 16-byte aligned");
+        // the kernel addresses staged rows with 32-bit byte offsets from the segment pointers
+        const int64_t lda_max = g->lda > g->lda2 ? g->lda : g->lda2, ldw_max = g->ldw > g->ldw2 ? g->ldw : g->ldw2;
+        VFR_REQUIRE((g->M * lda_max + MBK) * 4 < (1ll << 32) && (4ll * g->lstm_H * ldw_max + MBK) * 4 < (1ll << 32), VFR_EUNSUPPORTED,
+                    "lstm_step_pair: operand larger than 4 GB (rows x leading dimension); split the batch");
     }
     ProfScope prof(g0.site, st);
     GemmPair gp{{g0, g1}};
