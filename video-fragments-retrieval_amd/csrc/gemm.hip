@@ -9,6 +9,7 @@
 // Used by: visual MLP (model/models.py:21-26), BiLSTM input/recurrent projections and lang_fc
 // (model/models.py:40-47), BERT-branch Linear (:31), VGG fc6/fc7 (get_rgb_features.py:126).
 #include "vfr_common.h"
+#include <type_traits>
 #include "vfr_math.h"
 
 namespace vfr {
@@ -278,6 +279,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             woff2[i] = (unsigned)((nw * g.ldw2 + kk2) * 4);
         }
         wrow[i] = g.W + nw * g.ldw + kk;
+        if (!LSTM) woff1[i] = (unsigned)(((nw - n0) * g.ldw + kk) * 4);     // dense: from the tile's first row (gload_full)
     }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -289,16 +291,25 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             aoff1[i] = (unsigned)(((g.lstm_xrow ? (int64_t)g.lstm_xrow[ma] : ma) * g.lda + kk1) * 4);
         }
         arow[i] = CONV ? g.A : g.A + ma * g.lda + kk;
+        if (!LSTM && !CONV) aoff1[i] = (unsigned)(((ma - m0) * g.lda + kk) * 4);
     }
     auto gload_full = [&](int k0) {
+        // aligned operands: uniform tile base (scalar registers) + the thread's fixed 32-bit offset inside the tile's rows
+        // (at most 127 rows of lda floats: gemm_nt checks that this fits 32 bits) -- no vector address arithmetic per K-tile
+        const char *ba = reinterpret_cast<const char *>(g.A + m0 * g.lda + k0);
+        const char *bw = reinterpret_cast<const char *>(g.W + (int64_t)n0 * g.ldw + k0);
+        // (the empty asm keeps the 32-bit offset a 32-bit register inside the loop: hoisted as a zero-extended pair it would be
+        // added to the base with two-pass 64-bit vector adds instead of going into the load's scalar-base address form)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            if (VEC) ra[i] = *reinterpret_cast<const float4 *>(arow[i] + k0);
+            asm volatile("" : "+v"(aoff1[i]));
+            if (VEC) ra[i] = *reinterpret_cast<const float4 *>(ba + aoff1[i]);
             else     ra[i] = make_float4(arow[i][k0], arow[i][k0 + 1], arow[i][k0 + 2], arow[i][k0 + 3]);
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            if (VEC) rw[i] = *reinterpret_cast<const float4 *>(wrow[i] + k0);
+            asm volatile("" : "+v"(woff1[i]));
+            if (VEC) rw[i] = *reinterpret_cast<const float4 *>(bw + woff1[i]);
             else     rw[i] = make_float4(wrow[i][k0], wrow[i][k0 + 1], wrow[i][k0 + 2], wrow[i][k0 + 3]);
         }
     };
@@ -491,8 +502,10 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) frag_read(0, d, d % RING);
         }
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cb = kt & 1, nb = cb ^ 1;
+        // two K-tiles per trip, so the LDS buffer of every read and write is a compile-time constant and folds into the
+        // instruction's immediate offset (a run-time buffer index cost 10-15 vector adds per K-tile)
+        auto ktile = [&](int kt, auto cbc) {
+            constexpr int cb = decltype(cbc)::value, nb = cb ^ 1;
 #pragma unroll
             for (int k4 = 0; k4 < NS; ++k4) {
                 const int sn = k4 + DEPTH;                   // slice whose fragments are fetched now
@@ -511,7 +524,13 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 if (k4 == 1) swrite(nb);
                 if (k4 == VFR_GLOAD_SLICE) { const int t2 = kt + 2 < nk ? kt + 2 : nk - 1; gload_main(t2 * MBK); }
             }
+        };
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            ktile(kt, std::integral_constant<int, 0>{});
+            ktile(kt + 1, std::integral_constant<int, 1>{});
         }
+        if (kt < nk) ktile(kt, std::integral_constant<int, 0>{});
         if (!CONV && !LSTM && (g.K % MBK)) {   // partial last tile: guarded loads, zero padded (fma(0,0,acc) == acc)
             __syncthreads();
             gload_tail(nk_full * MBK);
@@ -803,6 +822,8 @@ int gemm_nt_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
     }
     if (g0.M == 0 || g0.N == 0) return VFR_OK;
     VFR_REQUIRE(g0.A && g0.W && g0.out && g1.A && g1.W && g1.out, VFR_EINVAL, "gemm_nt_pair: bad argument");
+    VFR_REQUIRE(g0.lda < (1ll << 22) && g0.ldw < (1ll << 22) && g1.lda < (1ll << 22) && g1.ldw < (1ll << 22), VFR_EUNSUPPORTED,
+                "gemm_nt_pair: leading dimension of 4M floats or more");
     ProfScope prof(g0.site, st);
     GemmPair gp{{g0, g1}};
     dim3 grid((unsigned)cdiv(g0.M, MBM), (unsigned)cdiv(g0.N, MBN), 2);
@@ -818,6 +839,8 @@ int gemm_nt_splitk_pair(const GemmArgs &g0, const GemmArgs &g1, int nsplit, int6
     VFR_REQUIRE(g0.A && g0.W && g0.out && g1.A && g1.W && g1.out && g0.M == g1.M && g0.N == g1.N && g0.K == g1.K && nsplit >= 1 &&
                     nsplit <= 16 && g0.epi == EPI_NONE && g1.epi == EPI_NONE && !g0.Cin && !g1.Cin, VFR_EINVAL,
                 "gemm_nt_splitk_pair: bad argument");
+    VFR_REQUIRE(g0.lda < (1ll << 22) && g0.ldw < (1ll << 22) && g1.lda < (1ll << 22) && g1.ldw < (1ll << 22), VFR_EUNSUPPORTED,
+                "gemm_nt_splitk_pair: leading dimension of 4M floats or more");
     VFR_REQUIRE(g0.K % (4 * nsplit) == 0 && gemm_vec_ok(g0) && gemm_vec_ok(g1), VFR_EUNSUPPORTED,
                 "gemm_nt_splitk_pair: K must be a multiple of 4 * nsplit, operands 16-byte aligned with strides in whole float4");
     ProfScope prof(g0.site, st);
@@ -834,6 +857,7 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
     VFR_REQUIRE(g.A && g.W && g.out && g.M > 0 && g.N > 0 && g.K >= 0, VFR_EINVAL, "gemm_nt: bad argument");
     VFR_REQUIRE(!(g.epi & (EPI_BIAS | EPI_BIAS2)) || g.bias, VFR_EINVAL, "gemm_nt: bias flag without bias");
     VFR_REQUIRE(!(g.epi & EPI_BIAS2) || g.bias2, VFR_EINVAL, "gemm_nt: bias2 flag without bias2");
+    VFR_REQUIRE(g.lda < (1ll << 22) && g.ldw < (1ll << 22), VFR_EUNSUPPORTED, "gemm_nt: leading dimension of 4M floats or more");
     ProfScope prof(g.site, st);
     dim3 grid((unsigned)cdiv(g.M, MBM), (unsigned)cdiv(g.N, MBN));
     if (g.conv_cin > 0) {                      // implicit-GEMM convolution: MFMA kernel only
