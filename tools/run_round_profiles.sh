@@ -12,18 +12,4 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch --
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $o/pmc_write.json 2> $o/pmc_write.err && echo "write ok"
 python tools/pmc_traffic.py $o/pmc_fetch $o/pmc_write $o/pmc_traffic.json "profiles/${tag}_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) of bench.py --steps 2 --warmup 1, bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; a committed profile, not measured in this run" > /dev/null && echo "traffic ok"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $o/pmc_sq -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $o/pmc_sq.json 2> $o/pmc_sq.err && echo "sq ok"
-python - "$o" <<'PY'
-import csv, glob, collections, sys, json
-o = sys.argv[1]
-f = glob.glob(o + '/pmc_sq/*/*counter_collection.csv')[0]
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
-for r in csv.DictReader(open(f)):
-    k = r['Kernel_Name'].split('(')[0][:70]
-    agg[k][r['Counter_Name']] += float(r['Counter_Value']); n[k].add(r['Dispatch_Id'])
-with open(o + '/pmc_sq.txt', 'w') as out:
-    for k, c in sorted(agg.items(), key=lambda kv: -kv[1].get('SQ_BUSY_CYCLES', 0))[:14]:
-        l = len(n[k])
-        busy = c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(c.get('SQ_BUSY_CYCLES', 1), 1) / 4
-        out.write(f"{k:70s} launches {l:4d}  mfma_busy/(4*sq_busy) {busy:6.3f}  " + "  ".join(f"{a}={v / l:.4g}" for a, v in sorted(c.items())) + "\n")
-print(open(o + '/pmc_sq.txt').read()[:3000])
-PY
+python tools/pmc_sq_summary.py "$o"

@@ -142,7 +142,7 @@ int main()
     float *out, *gmem; unsigned long long *ticks;
     hipMalloc(&out, sizeof(float) * 512 * 256); hipMalloc(&ticks, 16); hipMalloc(&gmem, 65536 * 4 + 64);
     hipMemset(gmem, 0, 65536 * 4 + 64);
-    printf("s_memtime ticks (100 MHz); one 512-thread workgroup per CU: waves 0-3 stream v_mfma_f32_16x16x4_f32, waves 4-7 the other class\n");
+    printf("s_memtime ticks (= core clocks here: 32 per back-to-back 16x16x4 MFMA); one 512-thread workgroup per CU: waves 0-3 stream v_mfma_f32_16x16x4_f32, waves 4-7 the other class\n");
     run<X_FMA>("v_fma_f32", out, ticks, gmem, 0);
     run<X_PKFMA>("v_pk_fma_f32", out, ticks, gmem, 0);
     run<X_EXP>("v_exp_f32", out, ticks, gmem, 0);
