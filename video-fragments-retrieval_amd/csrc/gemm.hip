@@ -152,9 +152,10 @@ __device__ unsigned long long g_gemm_stamps[4];
 // work on that stall.
 // NARROW = 64-column workgroup tile, the four waves stacked along M (each wave still 16*TI x 64): for operands with N <= 64
 // (VGG conv1_1 / conv1_2), where the 128-column tile would spend half of every MFMA on columns that do not exist.
-template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false, bool NARROW = false, bool TRAIN = false>
+template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false, bool NARROW = false, bool TRAIN = false, bool CFAST = false>
 __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
+    static_assert(!CFAST || CONV, "CFAST: the convolution loader for C_in a multiple of 32");
     static_assert(!TRAIN || LSTM, "TRAIN: the fused LSTM step that also stores its gates");
     static_assert(!NARROW || (MI == 1 && !LSTM && !PP), "narrow tile: 128 x 64 only");
     constexpr int TBM = NARROW ? 128 * MI : (MI ? 64 * MI : 32);    // tile rows (MI = 0: the 32-row tile, one row tile per wave)
@@ -216,6 +217,15 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     const int l15 = lane & 15, lq = lane >> 4;
     f32x4 acc[TI][4];
     auto init_acc = [&]() {
+#ifdef VFR_LSTM_NOGATHER      /* TIMING EXPERIMENT ONLY (wrong results): accumulators start from zero, no table gather */
+        if (LSTM && g.lstm_tok) {
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return;
+        }
+#endif
         if (LSTM && g.lstm_tok) {
             // chains start from the vocabulary input-projection table: P[lstm_tok[row]][tile column].  Two batched load
             // rounds (all table-row indices, then all accumulators), not dependent pairs one after the other.
@@ -329,6 +339,11 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // k's share one tap (conv_cin % 4 == 0); loads are unconditional from a clamped address, then zero-selected.
     int cn[NA], coy[NA], cox[NA];
     bool crow_ok[NA];
+    // CFAST (C_in % 32 == 0): a K-tile lies inside ONE filter tap, so the tap, its pixel displacement and the channel offset
+    // are scalar per tile; per staged row only a 9-bit mask of the taps that fall inside the image and a fixed 32-bit offset
+    // (from the tile's first pixel, biased by one image row + 1 so that it stays non-negative under every displacement) remain
+    unsigned ctap[NA], coffb[NA];
+    const int cbias = CFAST ? (g.conv_w + 1) * g.conv_cin : 0;          // floats
     if (CONV) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -341,8 +356,40 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             const int rem = (int)(pc - (int64_t)cn[i] * hw);
             coy[i] = rem / g.conv_w;
             cox[i] = rem - coy[i] * g.conv_w;
+            if (CFAST) {
+                unsigned mask = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = coy[i] + t / 3 - 1, ix = cox[i] + t % 3 - 1;
+                    if (crow_ok[i] && iy >= 0 && iy < g.conv_h && ix >= 0 && ix < g.conv_w) mask |= 1u << t;
+                }
+                ctap[i] = mask;
+                coffb[i] = (unsigned)(((crow_ok[i] ? (int64_t)row : 0) * g.conv_cin + (f & 7) * 4 + cbias) * 4);
+            }
         }
     }
+    const int ctpt = CFAST ? g.conv_cin / MBK : 1;                      // K-tiles per tap
+    auto gload_conv_fast = [&](int k0) {
+        const int kt = k0 / MBK, tap = kt / ctpt, ci0 = (kt - tap * ctpt) * MBK;
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;             // tap / 3 for tap < 9
+        const int dpix = (ky - 1) * g.conv_w + (kx - 1);
+        const unsigned dbytes = (unsigned)(dpix * g.conv_cin * 4), tbit = 1u << tap;
+        // (m0 + dpix) * C_in + ci0 - bias may lie before the tensor: only ever dereferenced with an in-image offset added
+        const char *ba = reinterpret_cast<const char *>(g.A + ((m0 + dpix) * g.conv_cin + ci0 - cbias));
+        const char *bw = reinterpret_cast<const char *>(g.W + (int64_t)n0 * g.ldw + k0);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const bool ok = (ctap[i] & tbit) != 0;
+            // outside the image: the row's own pixel (always inside), zeroed when the registers go to LDS
+            ra[i] = *reinterpret_cast<const float4 *>(ba + (ok ? coffb[i] : coffb[i] - dbytes));
+            za[i] = !ok;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            asm volatile("" : "+v"(woff1[i]));
+            rw[i] = *reinterpret_cast<const float4 *>(bw + woff1[i]);
+        }
+    };
     auto gload_conv = [&](int k0) {
         const int kk = (tid & 7) * 4, k = k0 + kk;
         const bool kok = k < g.K;
@@ -452,7 +499,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // main loop over the FULL K-tiles, branch-free: iteration kt prefetches tile min(kt+1, last) (the final
     // iteration re-reads its own tile, which is harmless) so no control-flow join sits between the loads and the
     // MFMA block -- a join there makes the compiler drain vmcnt(0) before the first MFMA.
-    auto gload_main = [&](int k0) { if (LSTM) gload_seg(k0); else if (CONV) gload_conv(k0); else gload_full(k0); };
+    auto gload_main = [&](int k0) { if (LSTM) gload_seg(k0); else if (CFAST) gload_conv_fast(k0); else if (CONV) gload_conv(k0); else gload_full(k0); };
     if (PP) {
         // group g runs  C0 L1 C1 L2 ... C(nk-1)  delayed by g phases;  Ck = MFMA block on K-tile k (LDS), Lk = K-tile k from
         // registers to LDS + issue the loads of K-tile k+1.  One workgroup barrier per phase.
@@ -676,8 +723,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp)
     gemm_nt_mfma_body<VEC, false>(g);         // kernarg array there (an s_load + lgkmcnt(0) would also drain the LDS reads)
 }
 
-template <int MI = 2, bool NARROW = false>
-__global__ __launch_bounds__(256, MI <= 1 ? 3 : 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true, false, MI, false, NARROW>(g); }
+template <int MI = 2, bool NARROW = false, bool CFAST = false>
+__global__ __launch_bounds__(256, MI <= 1 ? 3 : 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true, false, MI, false, NARROW, false, CFAST>(g); }
 
 template <int MI>
 __global__ __launch_bounds__(256, MI <= 1 ? 3 : VFR_LSTM_WAVES) void lstm_step_mfma_pair(GemmPair gp)
@@ -864,17 +911,25 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
         VFR_REQUIRE((g.conv_cin & 3) == 0 && g.K == 9 * g.conv_cin && (g.ldw & 3) == 0 &&
                         ((((uintptr_t)g.A) | ((uintptr_t)g.W)) & 15) == 0,
                     VFR_EINVAL, "gemm_nt(conv): needs Cin %% 4 == 0, K = 9*Cin and 16-byte aligned operands");
+        // C_in a multiple of 32 (every VGG layer but the first): the loader with scalar tap arithmetic
+        const bool cf = (g.conv_cin % MBK) == 0 && (int64_t)(g.conv_w + 1 + MBM + 2 * g.conv_w + 2) * g.conv_cin * 4 < (1ll << 31);
+#define VFR_CONV(MI_, NARROW_, GRID_, ARGS_)                                                                            \
+        do {                                                                                                            \
+            if (cf) hipLaunchKernelGGL((conv3x3_nhwc_mfma<MI_, NARROW_, true>), GRID_, dim3(256), 0, st, ARGS_);         \
+            else    hipLaunchKernelGGL((conv3x3_nhwc_mfma<MI_, NARROW_, false>), GRID_, dim3(256), 0, st, ARGS_);        \
+        } while (0)
         if (g.N <= 64) {                                      // conv1_x: 128 x 64 tiles, no MFMA spent on absent columns
-            hipLaunchKernelGGL((conv3x3_nhwc_mfma<1, true>), dim3(grid.x, 1), dim3(256), 0, st, g);
+            VFR_CONV(1, true, dim3(grid.x, 1), g);
         } else if ((int64_t)grid.x * grid.y < 384) {          // under 1.5 workgroups per CU: 64-row tiles (as the dense GEMM)
-            hipLaunchKernelGGL((conv3x3_nhwc_mfma<1, false>), dim3((unsigned)cdiv(g.M, 64), grid.y), dim3(256), 0, st, g);
+            VFR_CONV(1, false, dim3((unsigned)cdiv(g.M, 64), grid.y), g);
         } else if (grid.y > 1 && grid.y <= 16 && grid.x >= 64) {     // XCD-aware tile order (see xcd_cols): activations stream once
             GemmArgs gx = g;
             gx.xcd_cols = (int)grid.y;
-            hipLaunchKernelGGL((conv3x3_nhwc_mfma<2, false>), dim3((unsigned)(cdiv(grid.x, 8) * 8 * grid.y)), dim3(256), 0, st, gx);
+            VFR_CONV(2, false, dim3((unsigned)(cdiv(grid.x, 8) * 8 * grid.y)), gx);
         } else {
-            hipLaunchKernelGGL((conv3x3_nhwc_mfma<2, false>), grid, dim3(256), 0, st, g);
+            VFR_CONV(2, false, grid, g);
         }
+#undef VFR_CONV
         VFR_CHECK_LAUNCH("conv3x3_nhwc_mfma");
         return VFR_OK;
     }
