@@ -451,6 +451,30 @@ def test_file_dataset_pools_on_gpu_and_evaluates(vfr, oracle, golden, mode, tmp_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("normlang", [False, True])
+def test_bilstm_few_queries_vector_chain(vfr, oracle, normlang):
+    """Batches of 1-4 queries (a serving request) take the vector-chain LSTM step (`lstm_small`): same bits as the MFMA tile
+    path forced on the same rows, and as the oracle; incl. an all-pad query and the normalised-length embedding."""
+    sd = synth.model_weights(4096, seed=13, normalize_lang=normlang)
+    tokens = synth.query_tokens(4, seed=13)
+    tokens[2, :] = 0                                                  # an all-pad query
+    lt = sd.get("learnable_length.weight")
+    rest = (dev(sd["word_embedding.weight"]), {k: dev(v) for k, v in lstm_of(sd).items()}, dev(sd["lang_fc.weight"]),
+            dev(sd["lang_fc.bias"]), dev(lt) if lt is not None else None)
+    want = oracle.bilstm_final(tokens, sd["word_embedding.weight"], lstm_of(sd), sd["lang_fc.weight"], sd["lang_fc.bias"], lt)
+    for B in (1, 2, 3, 4):
+        try:
+            vfr.set_option("lstm_small", 4)
+            small = vfr.bilstm_final(dev(tokens[:B]), *rest)
+            vfr.set_option("lstm_small", 0)
+            tiles = vfr.bilstm_final(dev(tokens[:B]), *rest)
+        finally:
+            vfr.set_option("lstm_small", 2)
+        assert torch.equal(small.view(torch.int32), tiles.view(torch.int32)), B
+        assert same(small, want[:B]), B
+
+
+@pytest.mark.gpu
 def test_bilstm_tile_shapes_agree(vfr, oracle):
     """The fused LSTM step picks 32-, 64- or 128-row tiles by batch size; all are the same chains.  Forced either way on one
     batch: identical bits to each other and (on the rows the oracle is run for) to the oracle."""

@@ -145,13 +145,117 @@ __global__ __launch_bounds__(256) void unsort_rows_kernel(const float *__restric
     out[i] = hs[src * 2 * H + j];
 }
 
+// ---- a handful of queries (one serving request): the step as a vector chain ----------------------------------------
+// With B <= 4 rows a 32-row MFMA tile is 3-13 % full and, worse, a wave walks its K = E + H chain 4 MFMAs (128 cycles) per
+// 4 k's: 34 us per step whatever the batch.  Here a lane owns ONE gate column of one direction and runs the canonical chain
+// itself -- acc = fma(x_k, W_ih[c][k], acc) over E, then fma(h_k, W_hh[c][k], acc) over H -- for all RB rows: [x_t | h]
+// of the rows is staged in LDS once and read back as broadcasts (scalar loads cannot be kept in flight: every chunk paid
+// their latency), the weights come from a chunk-major copy [(E + H) / 4][4H][4] made once per call (one coalesced 16-byte
+// load per lane and 4 k's), fetched PF chunks ahead.  17 us per step at one query, 25 at two (default limit), 38 at four.  A wave = 4 gates x 16 units, so the four pre-activations of a
+// unit meet through 1 KB of LDS and 16 lanes finish the cells.  Same chains, same bits (test: lstm_small = 0 vs 4).
+struct SmallLstm {
+    const float *X;                       // [B*T, E] embedded tokens
+    const float *WT[2];                   // [(E + H) / 4][4H][4]: chunk c, column col, k = 4c..4c+3 (W_ih over E, then W_hh)
+    const float *bih[2], *bhh[2];
+    const float *hin, *cin;               // h [B, 2H] (direction d at column d*H), c [2][B][H]
+    float *hout, *cout;
+    int B, T, E, H, step, recurrent;      // recurrent = 0: first step, h_0 = 0 (no h terms in the chain)
+};
+// W [rows, K] row-major -> out [(K/4)][rows][4]: the four consecutive k's of a column adjacent, columns consecutive
+__global__ __launch_bounds__(256) void pack_k4_kernel(const float *__restrict__ W, int64_t rows, int K, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (k4, row), row fastest: coalesced stores
+    const int64_t nk4 = K / 4;
+    if (i >= nk4 * rows) return;
+    const int64_t k4 = i / rows, row = i - k4 * rows;
+    reinterpret_cast<float4 *>(out)[i] = *reinterpret_cast<const float4 *>(W + row * K + 4 * k4);
+}
+
+template <int RB>
+__global__ __launch_bounds__(64) void lstm_step_small_kernel(SmallLstm a)
+{
+    // chunks (of 4 k's, one 16-byte load per lane) in flight: the weights stream from L2 / Infinity Cache at ~0.6 us latency,
+    // and with one wave per CU only what is in flight counts -- 8 chunks gave 25 us per step, the chip-wide 1 MB in flight
+    constexpr int PF = 32, XF = 4;        // XF: LDS broadcast reads of [x | h] issued this many chunks ahead
+    __shared__ float pre[RB][4][16];
+    extern __shared__ __attribute__((aligned(16))) float xh[];          // [RB][E + H]: the rows' chain inputs
+    const int lane = threadIdx.x, gate = lane >> 4, ul = lane & 15, d = blockIdx.y;
+    const int unit = blockIdx.x * 16 + ul, H = a.H, E = a.E, G = 4 * H;
+    const int uc = unit < H ? unit : H - 1;
+    const int t = d ? a.T - 1 - a.step : a.step;
+    const float4 *wt = reinterpret_cast<const float4 *>(a.WT[d]) + (size_t)gate * H + uc;
+    const float *xr[RB], *hr[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int rr = r < a.B ? r : 0;
+        xr[r] = a.X + ((size_t)rr * a.T + t) * E;
+        hr[r] = a.hin + (size_t)rr * 2 * H + (size_t)d * H - E;          // indexed by the chain position k >= E
+    }
+    const int nchunk = (a.recurrent ? E + H : E) / 4;
+    float acc[RB];
+    float4 w[PF], xq[XF][RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.0f;
+    auto fetch = [&](int slot, int c) {                                  // chunk index clamped: a redundant load, no branch
+        const int cc = c < nchunk ? c : nchunk - 1;
+        w[slot] = wt[(size_t)cc * G];
+    };
+    auto xfetch = [&](int slot, int c) {
+        const int cc = c < nchunk ? c : nchunk - 1;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) xq[slot][r] = *reinterpret_cast<const float4 *>(xh + r * (E + H) + 4 * cc);   // LDS broadcast
+    };
+    auto chain = [&](int slot, int xs) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float4 x = xq[xs][r];
+            acc[r] = __builtin_fmaf(x.x, w[slot].x, acc[r]); acc[r] = __builtin_fmaf(x.y, w[slot].y, acc[r]);
+            acc[r] = __builtin_fmaf(x.z, w[slot].z, acc[r]); acc[r] = __builtin_fmaf(x.w, w[slot].w, acc[r]);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < PF; ++j) fetch(j, j);
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll 2
+        for (int c = lane; c < nchunk; c += 64)
+            *reinterpret_cast<float4 *>(xh + r * (E + H) + 4 * c) = *reinterpret_cast<const float4 *>((4 * c < E ? xr[r] : hr[r]) + 4 * c);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < XF; ++j) xfetch(j, j);
+    int base = 0;
+    for (; base + PF <= nchunk; base += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) { chain(j, j % XF); fetch(j, base + j + PF); xfetch(j % XF, base + j + XF); }
+    }
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+        if (base + j < nchunk) { chain(j, j % XF); xfetch(j % XF, base + j + XF); }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) pre[r][gate][ul] = acc[r];
+    __syncthreads();
+    // cells: lane (row r = lane >> 4, unit ul); RB <= 4 rows fit one wave
+    const int r = lane >> 4;
+    if (r < RB && r < a.B && unit < H) {
+        const float *bi = a.bih[d], *bh = a.bhh[d];
+        const float ig = c_sigmoidf(pre[r][0][ul] + (bi[unit] + bh[unit]));
+        const float fg = c_sigmoidf(pre[r][1][ul] + (bi[H + unit] + bh[H + unit]));
+        const float gg = c_tanhf(pre[r][2][ul] + (bi[2 * H + unit] + bh[2 * H + unit]));
+        const float og = c_sigmoidf(pre[r][3][ul] + (bi[3 * H + unit] + bh[3 * H + unit]));
+        const size_t ci = ((size_t)d * a.B + r) * H + unit;
+        const float cn = __builtin_fmaf(fg, a.cin[ci], ig * gg);
+        a.cout[ci] = cn;
+        a.hout[(size_t)r * 2 * H + (size_t)d * H + unit] = og * c_tanhf(cn);
+    }
+}
+
 // Vocabularies up to this many entries get the input-projection table (P = emb x W_ih^T per entry, 2 directions):
 // 2 x 32768 x 4096 floats = 1 GB at H = 1000 -- nothing on a 288 GB part, and far fewer rows than B*T once B is large.
 constexpr int VOCAB_TABLE_MAX = 32768;
 static bool use_vocab_table(int64_t B, int T, int vocab) { return vocab <= VOCAB_TABLE_MAX && (int64_t)vocab <= 4 * B * T; }
 
 struct LstmWs {
-    float *X, *gates, *c, *c2, *hcat, *hcat2, *hfinal, *xv, *wperm, *ptab;
+    float *X, *gates, *c, *c2, *hcat, *hcat2, *hfinal, *xv, *wperm, *ptab, *wt;
     int *tokidx;
     int64_t *tok_ext;
     int *len, *row_of, *xrow, *mcount, *hist;
@@ -184,6 +288,7 @@ static LstmWs carve(void *base, int64_t B, int T, int E, int H, int vocab)
         w.ptab = take(2 * (size_t)vocab * np);
         w.tokidx = reinterpret_cast<int *>(take_b(R * T * sizeof(int)));
     }
+    if (B <= 4) w.wt = take((size_t)2 * (E + H) * 4 * H);       // k-major weights of the vector-chain step (a few queries)
     w.total = off;
     return w;
 }
@@ -218,6 +323,48 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
     const int G = 4 * H;
 
     VFR_REQUIRE(T <= 1024, VFR_EUNSUPPORTED, "vfr_bilstm_final_f32: T=%d > 1024", T);
+    if (B <= vfr::opt_lstm_small() && B <= 4 && (E % 4) == 0 && (H % 4) == 0 && w.wt && (size_t)4 * (E + H) * 4 <= 48 * 1024) {
+        // a handful of queries: every row steps through all T tokens with the vector-chain step (no sorting, no pad row)
+        if (hipMemsetAsync(w.c, 0, (size_t)2 * B * H * sizeof(float), st) != hipSuccess ||
+            hipMemsetAsync(w.hcat, 0, (size_t)B * 2 * H * sizeof(float), st) != hipSuccess)
+            return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: buffer initialisation failed");
+        {
+        vfr::ProfScope prof(vfr::SITE_EMBED, st);
+        hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(B * T, 256)), dim3(256), 0, st, tokens, B * T, vocab, emb, len_tab,
+                           E, w.X);
+        }
+        VFR_CHECK_LAUNCH("embed_kernel");
+        float *wt[2] = {w.wt, w.wt + (size_t)(E + H) * 4 * H};
+        {
+        vfr::ProfScope prof(vfr::SITE_GEMM_LSTM_IN, st);
+        for (int d = 0; d < 2; ++d) {                                   // [4H, E] and [4H, H] -> chunk-major [(E + H) / 4][4H][4]
+            const int64_t n1 = (int64_t)(E / 4) * 4 * H, n2 = (int64_t)(H / 4) * 4 * H;
+            hipLaunchKernelGGL(vfr::pack_k4_kernel, dim3((unsigned)vfr::cdiv(n1, 256)), dim3(256), 0, st, d ? Wih_b : Wih_f, 4 * (int64_t)H, E, wt[d]);
+            hipLaunchKernelGGL(vfr::pack_k4_kernel, dim3((unsigned)vfr::cdiv(n2, 256)), dim3(256), 0, st, d ? Whh_b : Whh_f, 4 * (int64_t)H, H,
+                               wt[d] + (size_t)E * 4 * H);
+        }
+        }
+        VFR_CHECK_LAUNCH("pack_k4_kernel");
+        float *hin = w.hcat, *hout = w.hcat2, *cin = w.c, *cout = w.c2;
+        for (int step = 0; step < T; ++step) {
+            vfr::SmallLstm a{w.X, {wt[0], wt[1]}, {bih_f, bih_b}, {bhh_f, bhh_b}, hin, cin, hout, cout,
+                             (int)B, T, E, H, step, (step == 0 && vfr::opt_lstm_skip0()) ? 0 : 1};
+            vfr::ProfScope prof(vfr::SITE_GEMM_LSTM_REC, st);
+            const dim3 grid((unsigned)vfr::cdiv(H, 16), 2);
+            switch ((int)B) {
+            case 1: hipLaunchKernelGGL(vfr::lstm_step_small_kernel<1>, grid, dim3(64), (size_t)1 * (E + H) * 4, st, a); break;
+            case 2: hipLaunchKernelGGL(vfr::lstm_step_small_kernel<2>, grid, dim3(64), (size_t)2 * (E + H) * 4, st, a); break;
+            default: hipLaunchKernelGGL(vfr::lstm_step_small_kernel<4>, grid, dim3(64), (size_t)4 * (E + H) * 4, st, a); break;
+            }
+            float *tmp = hin; hin = hout; hout = tmp;
+            tmp = cin; cin = cout; cout = tmp;
+        }
+        VFR_CHECK_LAUNCH("lstm_step_small_kernel");
+        vfr::GemmArgs g{};
+        g.A = hin; g.lda = 2 * H; g.W = Wfc; g.ldw = 2 * H; g.out = out; g.ldo = D; g.M = B; g.N = D; g.K = 2 * H;
+        g.bias = bfc; g.epi = vfr::EPI_BIAS; g.site = vfr::SITE_GEMM_LANG_FC;
+        return vfr::gemm_nt(g, st);
+    }
     const int64_t R = B + 1;                                // GEMM rows: row 0 = all-pad query, then queries by length
     // tokens + one all-pad query -> embeddings of R queries
     if (hipMemcpyAsync(w.tok_ext, tokens, (size_t)B * T * sizeof(int64_t), hipMemcpyDeviceToDevice, st) != hipSuccess ||
