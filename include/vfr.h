@@ -131,10 +131,19 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
  *   dtype VFR_MFMA_BF16 bf16 operands, fp32 accumulate (BASELINE config 5): count_lt from the approximate
  *                       distances, top-k = exact re-rank of the k + 28 best approximate candidates.  Needs D = 100,
  *                       max_clips <= 21, num_rank in {0, 2}, k <= 253; VFR_EUNSUPPORTED otherwise.
- * Arguments as vfr_score_topk_f32.                                                              */
+ * Arguments as vfr_score_topk_f32.
+ * dtype | VFR_MFMA_BANK_READY: the caller states that `workspace` was last used by a pre-filter call (one for which
+ * vfr_score_topk_mfma_prefilter returned 1) on exactly this bank -- same V contents, offsets and base dtype, any Nq / k --
+ * and has not been written since: the bank-side products (mean, centred rows, norms; they sit at the front of the
+ * workspace at offsets that depend on total_clips alone) are reused instead of recomputed.  For serving many query batches
+ * against one resident bank (0.1-0.15 ms per call at 210 000 clips).  Not checked.
+ * vfr_score_topk_mfma_prefilter: 1 if a call with these shapes runs the pre-filter (and therefore leaves the bank-side
+ * products in its workspace), 0 if it is handed to the exact kernels.                            */
 #define VFR_MFMA_F32 0
 #define VFR_MFMA_BF16 1
+#define VFR_MFMA_BANK_READY 0x100
 size_t vfr_score_topk_mfma_workspace_bytes(int64_t Nq, int Nv, int total_clips, int k);
+int vfr_score_topk_mfma_prefilter(int64_t Nq, int Nv, int total_clips, int max_clips, int D, int num_rank, int k, int dtype);
 int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets,
                         const int64_t *moment_offsets, int Nv, int total_clips, int min_clips, int max_clips, int D,
                         float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,

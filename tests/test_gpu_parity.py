@@ -451,6 +451,51 @@ def test_file_dataset_pools_on_gpu_and_evaluates(vfr, oracle, golden, mode, tmp_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["mfma", "bf16"])
+def test_prefilter_bank_products_reused_only_while_valid(vfr, mode):
+    """Serving: query batches of different sizes against one resident bank and one workspace reuse the pre-filter's bank-side
+    products (VFR_MFMA_BANK_READY); an in-place edit of the embeddings, another bank object, or an exact-mode call in
+    between must recompute.  Every result == the same call on a fresh workspace."""
+    vfr.set_option("score_mfma_min", 0)
+    try:
+        rs = np.random.RandomState(3)
+        counts = rs.randint(1, 22, 300); counts[5] = 21
+        off = synth.clip_offsets(counts)
+        V = dev(rs.randn(int(off[-1]), 100).astype(np.float32) * 0.3 + 0.5)
+        bank = vfr.VideoBank(V.clone(), dev(off.astype(np.int32)))
+        ws = vfr.topk_workspace(200, 300, 50, DEV, total_clips=int(off[-1]))
+
+        def call(b, nq, workspace, k=50):
+            Q = dev(np.random.RandomState(nq).randn(nq, 100).astype(np.float32) * 0.3 + 0.5)
+            dense = vfr.score_moments(Q, b)
+            order = torch.argsort(dense, dim=1, stable=True)
+            rd = torch.stack([dense.gather(1, order[:, 7:8]).squeeze(1), dense.gather(1, order[:, 900:901]).squeeze(1)]).contiguous()
+            ri = torch.stack([order[:, 7], order[:, 900]]).contiguous()
+            return vfr.score_topk(Q, b, k, rd, ri, workspace=workspace, mode=mode)
+
+        def check(b, nq, expect_reuse):
+            before = getattr(ws, "_vfr_bank", None)
+            assert (before == b.prep_token(vfr.SCORE_MODES[mode])) == expect_reuse
+            got, want = call(b, nq, ws), call(b, nq, None)
+            for x, y in zip(got, want):
+                assert torch.equal(x, y)
+
+        check(bank, 200, False)
+        check(bank, 64, True)                       # same bank, smaller batch: reused
+        check(bank, 1, True)
+        bank.emb.mul_(1.5)                          # in-place edit: torch's version counter moves, products recomputed
+        check(bank, 64, False)
+        check(bank, 64, True)
+        bank2 = vfr.VideoBank(V * 0.5, dev(off.astype(np.int32)))
+        check(bank2, 64, False)                     # another bank through the same workspace
+        check(bank, 64, False)                      # ... and back: the workspace holds bank2's products
+        vfr.score_topk(dev(rs.randn(8, 100).astype(np.float32)), bank, 10, workspace=ws, mode="exact")
+        check(bank, 64, False)                      # the exact kernels carved the workspace their own way
+    finally:
+        vfr.set_option("score_mfma_min", 128)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("normlang", [False, True])
 def test_bilstm_few_queries_vector_chain(vfr, oracle, normlang):
     """Batches of 1-4 queries (a serving request) take the vector-chain LSTM step (`lstm_small`): same bits as the MFMA tile

@@ -42,6 +42,7 @@ SIGNATURES = {
     "vfr_score_topk_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "vfr_score_topk_f32": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i64, _i32, _vp, _vp, _i32,
                                   _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vfr_score_topk_mfma_prefilter": (_i32, [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "vfr_score_topk_mfma_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "vfr_score_topk_mfma": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i64, _i32, _vp, _vp, _i32,
                                    _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
@@ -254,6 +255,16 @@ class VideoBank:
         self.total_clips = int(self.emb.shape[0])
         self.id_base = int(id_base)
         self.dim = int(self.emb.shape[1])
+        VideoBank._serial += 1
+        self.serial = VideoBank._serial          # identity of this bank's contents for the workspace-side cache (score_topk)
+
+    _serial = 0
+
+    def prep_token(self, dtype: int):
+        """What must be unchanged for the bank-side products of the MFMA pre-filter to be reusable: this object, no in-place
+        torch edit of its tensors since, the base dtype."""
+        return (self.serial, self.emb.data_ptr(), self.emb._version, self.clip_off.data_ptr(), self.clip_off._version,
+                self.num_videos, self.total_clips, int(dtype))
 
 
 def slice_bank(bank: VideoBank, counts, v0: int, v1: int) -> VideoBank:
@@ -293,6 +304,7 @@ def score_own(Q: torch.Tensor, bank: VideoBank, own: torch.Tensor, eps: float = 
 # scoring mode of score_topk: "mfma" = fp32 MFMA pre-filter + exact re-scoring (bit-identical to "exact", the default),
 # "exact" = the exact VALU kernels only, "bf16" = bf16 MFMA operands, approximate (BASELINE config 5)
 SCORE_MODES = {"exact": None, "mfma": 0, "bf16": 1}
+MFMA_BANK_READY = 0x100                    # include/vfr.h VFR_MFMA_BANK_READY
 DEFAULT_SCORE_MODE = os.environ.get("VFR_SCORE_MODE", "mfma")
 
 
@@ -332,9 +344,19 @@ def score_topk(Q: torch.Tensor, bank: VideoBank, k: int, rank_dist=None, rank_id
               bank.total_clips, bank.min_clips, bank.max_clips, bank.dim, eps, bank.id_base, k, _ptr(od), _ptr(oi), R,
               _ptr(rank_dist), _ptr(rank_idx), _ptr(count_lt), _ptr(thr_seed))
     if dtype is None:
+        workspace._vfr_bank = None               # the exact kernels carve the workspace their own way
         _check(lib().vfr_score_topk_f32(*common, workspace.data_ptr(), nbytes, _stream()), "vfr_score_topk_f32")
     else:
-        _check(lib().vfr_score_topk_mfma(*common, dtype, workspace.data_ptr(), nbytes, _stream()), "vfr_score_topk_mfma")
+        # the bank-side products of the pre-filter stay in the workspace: a later call on the SAME bank object (and untouched
+        # tensors) with this workspace reuses them (VFR_MFMA_BANK_READY); anything else recomputes
+        token = bank.prep_token(dtype)
+        ready = getattr(workspace, "_vfr_bank", None) == token
+        pre = lib().vfr_score_topk_mfma_prefilter(Nq, bank.num_videos, bank.total_clips, bank.max_clips, bank.dim, R, k, dtype)
+        workspace._vfr_bank = None
+        _check(lib().vfr_score_topk_mfma(*common, dtype | (MFMA_BANK_READY if ready and pre else 0), workspace.data_ptr(), nbytes,
+                                         _stream()), "vfr_score_topk_mfma")
+        if pre:
+            workspace._vfr_bank = token
     return od, oi, count_lt
 
 

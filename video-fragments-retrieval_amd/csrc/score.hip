@@ -1409,22 +1409,26 @@ static MfmaWs carve_mfma(void *base, int64_t Nq, int Nv, int total_clips, int k)
     w.queue_cap = 16 * per < 128 ? 128 : 16 * per;                       // a quarter of the task's (query, video) pairs
     size_t off = 0;
     auto take = [&](size_t bytes) { char *p = static_cast<char *>(base) + off; off += align_up(bytes, 256); return p; };
-    w.zero_base = take(0);
+    // bank side first, at offsets that depend on the bank alone (total_clips): a caller that scores many query batches against
+    // one resident bank keeps these across calls (VFR_MFMA_BANK_READY)
     w.rv = reinterpret_cast<float *>(take(4));
-    w.fallback = reinterpret_cast<int *>(take((size_t)g * 4));
-    w.queue_cnt = reinterpret_cast<int *>(take((size_t)w.tasks * 4));
-    w.cnt_ws = reinterpret_cast<unsigned long long *>(take((size_t)MAX_RANK * Nq * 8));
-    w.zero_bytes = off;
     w.mean_rows = 512;
     w.mean_blocks = (int)cdiv(total_clips > 0 ? total_clips : 1, w.mean_rows);
     w.mu = reinterpret_cast<float *>(take(128 * 4));
     w.mean_partial = reinterpret_cast<double *>(take((size_t)w.mean_blocks * 128 * 8));
     w.vc = reinterpret_cast<float *>(take((size_t)total_clips * FAST_D * 4));
-    w.qc = reinterpret_cast<float *>(take((size_t)Nq * FAST_D * 4));
     w.va = reinterpret_cast<float *>(take((size_t)total_clips * 4));
+    w.vb = reinterpret_cast<unsigned short *>(take((size_t)total_clips * 128 * 2));
+    // zeroed at every call
+    w.zero_base = static_cast<char *>(base) + off;
+    const size_t z0 = off;
+    w.fallback = reinterpret_cast<int *>(take((size_t)g * 4));
+    w.queue_cnt = reinterpret_cast<int *>(take((size_t)w.tasks * 4));
+    w.cnt_ws = reinterpret_cast<unsigned long long *>(take((size_t)MAX_RANK * Nq * 8));
+    w.zero_bytes = off - z0;
+    w.qc = reinterpret_cast<float *>(take((size_t)Nq * FAST_D * 4));
     w.qmeta = reinterpret_cast<float4 *>(take((size_t)Nq * 16));
     w.tab = reinterpret_cast<unsigned *>(take((size_t)Nq * 2 * 21 * MF_TAB * 4));
-    w.vb = reinterpret_cast<unsigned short *>(take((size_t)total_clips * 128 * 2));
     w.queue = reinterpret_cast<unsigned long long *>(take((size_t)w.tasks * w.queue_cap * 8));
     w.topk_bytes = carve_topk(nullptr, Nq, Nv, k > 0 ? k + MF_EXTRA : 0).total;
     w.topk = take(w.topk_bytes);
@@ -1459,12 +1463,21 @@ size_t vfr_score_topk_mfma_workspace_bytes(int64_t Nq, int Nv, int total_clips, 
     return a > b ? a : b;
 }
 
+int vfr_score_topk_mfma_prefilter(int64_t Nq, int Nv, int total_clips, int max_clips, int D, int num_rank, int k, int dtype)
+{
+    dtype &= ~VFR_MFMA_BANK_READY;
+    return Nq > 0 && k >= 0 && num_rank >= 0 && vfr::mfma_applicable(D, max_clips, num_rank, k, Nv, total_clips) &&
+           vfr::mfma_worthwhile(Nv, dtype) && vfr::opt_score_fast();
+}
+
 int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets,
                         const int64_t *moment_offsets, int Nv, int total_clips, int min_clips, int max_clips, int D,
                         float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
                         const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, const int64_t *thr_seed,
                         int dtype, void *workspace, size_t workspace_bytes, vfr_stream_t stream)
 {
+    const bool bank_ready = (dtype & VFR_MFMA_BANK_READY) != 0;
+    dtype &= ~VFR_MFMA_BANK_READY;
     VFR_REQUIRE(dtype == VFR_MFMA_F32 || dtype == VFR_MFMA_BF16, VFR_EINVAL, "vfr_score_topk_mfma: dtype %d (0 = f32, 1 = bf16)", dtype);
     VFR_REQUIRE(workspace && workspace_bytes >= vfr_score_topk_mfma_workspace_bytes(Nq, Nv, total_clips, k), VFR_EWORKSPACE,
                 "vfr_score_topk_mfma: workspace %zu < %zu bytes", workspace_bytes,
@@ -1493,11 +1506,14 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
     m.queue_cap = mw.queue_cap; m.fallback = mw.fallback; m.vb = bf16 ? mw.vb : nullptr; m.rv = mw.rv; m.vc = mw.vc; m.qc = mw.qc;
     {
         vfr::ProfScope prof(vfr::SITE_SCORE_PREP, st);
-        hipLaunchKernelGGL(vfr::mfma_mean_partial_kernel, dim3((unsigned)mw.mean_blocks), dim3(1024), 0, st, V, total_clips, D, mw.mean_rows,
-                           mw.mean_partial);
-        hipLaunchKernelGGL(vfr::mfma_mean_final_kernel, dim3(1), dim3(1024), 0, st, mw.mean_partial, mw.mean_blocks, D, total_clips, mw.mu);
-        hipLaunchKernelGGL(vfr::mfma_prep_v_kernel, dim3((unsigned)vfr::cdiv(total_clips, 4)), dim3(256), 0, st, V, total_clips, D, eps,
-                           mw.mu, mw.vc, mw.va, mw.rv, bf16 ? mw.vb : nullptr);
+        if (!bank_ready) {                   // bank side: mean, centred rows, squared norms, the largest norm (bf16: the rounded copy)
+            if (hipMemsetAsync(mw.rv, 0, 4, st) != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: hipMemsetAsync failed");
+            hipLaunchKernelGGL(vfr::mfma_mean_partial_kernel, dim3((unsigned)mw.mean_blocks), dim3(1024), 0, st, V, total_clips, D, mw.mean_rows,
+                               mw.mean_partial);
+            hipLaunchKernelGGL(vfr::mfma_mean_final_kernel, dim3(1), dim3(1024), 0, st, mw.mean_partial, mw.mean_blocks, D, total_clips, mw.mu);
+            hipLaunchKernelGGL(vfr::mfma_prep_v_kernel, dim3((unsigned)vfr::cdiv(total_clips, 4)), dim3(256), 0, st, V, total_clips, D, eps,
+                               mw.mu, mw.vc, mw.va, mw.rv, bf16 ? mw.vb : nullptr);
+        }
         hipLaunchKernelGGL(vfr::mfma_prep_q_kernel, dim3((unsigned)vfr::cdiv(Nq, 16)), dim3(256), 0, st, Q, Nq, D, eps, mw.mu, mw.qc, mw.rv,
                            num_rank, rank_dist, mw.qmeta);
         if (num_rank > 0) {
