@@ -127,7 +127,8 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
  * (model/evaluate.py:53-58 as north_star's "MFMA batched query x clip GEMM"; csrc/score_mfma.h):
  *   dtype VFR_MFMA_F32  fp32 MFMA pre-filter with a rigorous error margin; whatever the margin cannot decide is
  *                       re-scored with the exact chain, so every output is BIT-IDENTICAL to vfr_score_topk_f32
- *                       (shapes the pre-filter is not built for are simply handed to vfr_score_topk_f32);
+ *                       (shapes the pre-filter is not built for are simply handed to vfr_score_topk_f32; 1-8 queries -- a
+ *                       serving request -- take a path of their own with lanes = clips / videos, equally exact);
  *   dtype VFR_MFMA_BF16 bf16 operands, fp32 accumulate (BASELINE config 5): count_lt from the approximate
  *                       distances, top-k = exact re-rank of the k + 28 best approximate candidates.  Needs D = 100,
  *                       max_clips <= 21, num_rank in {0, 2}, k <= 253; VFR_EUNSUPPORTED otherwise.
@@ -265,7 +266,7 @@ int vfr_math_f32(int op, const float *x, const float *y, float *out, int64_t n, 
  * launches), "lstm_tile" 0|1|2|3 (fused LSTM step tile rows: automatic | 64 | 128 | 32), "gemm_pp" 0|1 (experimental ping-pong
  * schedule of the large MFMA GEMMs, default 0), "score_pre_b" N (videos in the top-k threshold ladder's stage B; 0 = Nv/16
  * capped at 640), "score_tasks" N (wave-tasks the fused scorer's plan aims for; 0 = automatic), "lstm_skip0" 1|0 (the first LSTM step
- * skips its recurrent segment because h_0 = 0 | runs it), "lstm_small" N (batches of up to N <= 4 queries take the vector-chain LSTM step, default 2; 0: always the MFMA tiles), "score_mfma_min" N (vfr_score_topk_mfma hands banks of fewer than N videos to the exact kernels, default 128), "gemm_small" 0|64 (GEMMs of under 384 128-row tiles: 32-row tiles |
+ * skips its recurrent segment because h_0 = 0 | runs it), "score_smallq" N (vfr_score_topk_mfma, f32: batches of up to N <= 8 queries against banks of <= 21 clips per video are scored with lanes = clips / videos and a selection tree, default 8; 0: always the fused kernels), "lstm_small" N (batches of up to N <= 4 queries take the vector-chain LSTM step, default 2; 0: always the MFMA tiles), "score_mfma_min" N (vfr_score_topk_mfma hands banks of fewer than N videos to the exact kernels, default 128), "gemm_small" 0|64 (GEMMs of under 384 128-row tiles: 32-row tiles |
  * 64-row tiles), "lstm_xcd" 1|0 (XCD-aware workgroup order of the fused LSTM step | launch order) -- same bits either way.                                                                       */
 int vfr_set_option(const char *name, int value);
 int vfr_get_option(const char *name);

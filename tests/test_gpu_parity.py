@@ -451,6 +451,45 @@ def test_file_dataset_pools_on_gpu_and_evaluates(vfr, oracle, golden, mode, tmp_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nq", [1, 2, 3, 5, 8])
+def test_few_queries_scoring_path(vfr, nq):
+    """1-8 queries (a serving request) are scored with lanes = clips / videos and a selection tree over the key array
+    (`score_smallq`): top-k lists and rank counts bit-identical to the fused kernels (option off) and to dense + stable sort;
+    ragged clip counts, an empty video, duplicated videos (exact ties), k = 0 / 1 / 100 / more than there are moments, 1-4 rank keys."""
+    rs = np.random.RandomState(40 + nq)
+    for case in range(3):
+        nv = [1, 37, 700][case]
+        counts = rs.randint(0 if case else 1, 22, nv)
+        counts[rs.randint(nv)] = 21
+        off = synth.clip_offsets(counts)
+        V = rs.randn(int(off[-1]), 100).astype(np.float32) * 0.2
+        if nv > 2 and counts[0] and counts[0] == counts[nv - 1]:
+            V[off[nv - 1]:off[nv]] = V[off[0]:off[1]]
+        bank = vfr.VideoBank(dev(V), dev(off.astype(np.int32)))
+        Q = dev(rs.randn(nq, 100).astype(np.float32) * 0.2)
+        dense = vfr.score_moments(Q, bank)
+        total = dense.shape[1]
+        order = torch.argsort(dense, dim=1, stable=True)
+        R = [2, 1, 4][case]
+        pos = [int(rs.randint(0, total)) for _ in range(R)]
+        rd = torch.stack([dense.gather(1, order[:, p:p + 1]).squeeze(1) for p in pos]).contiguous()
+        ri = torch.stack([order[:, p] for p in pos]).contiguous()
+        for k in (0, 1, 100, total + 7 if total + 7 <= 448 else 300):
+            d, i, c = vfr.score_topk(Q, bank, k, rd, ri, mode="mfma")
+            try:
+                vfr.set_option("score_smallq", 0)
+                d2, i2, c2 = vfr.score_topk(Q, bank, k, rd, ri, mode="mfma")
+            finally:
+                vfr.set_option("score_smallq", 8)
+            assert c.tolist() == [[p] * nq for p in pos] and torch.equal(c, c2)
+            if k:
+                kk = min(k, total)
+                assert torch.equal(i[:, :kk], order[:, :kk]) and torch.equal(d[:, :kk], dense.gather(1, order[:, :kk]))
+                assert bool((i[:, kk:] == -1).all()) and bool(torch.isinf(d[:, kk:]).all())
+                assert torch.equal(i, i2) and torch.equal(d, d2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["mfma", "bf16"])
 def test_prefilter_bank_products_reused_only_while_valid(vfr, mode):
     """Serving: query batches of different sizes against one resident bank and one workspace reuse the pre-filter's bank-side

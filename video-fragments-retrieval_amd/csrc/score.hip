@@ -871,8 +871,9 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
 // appended only if it beats the running k-th key -- after the first round almost nothing is, so a query costs ~2 sorts.
 template <int KPL, bool PACKED>
 __global__ __launch_bounds__(256) void topk_merge_parts_kernel(const float *__restrict__ pd,
-                                                               const int64_t *__restrict__ pi, int64_t slot_stride, int G,
-                                                               int64_t Nq, int k, float *__restrict__ out_dist,
+                                                               const int64_t *__restrict__ pi, int64_t slot_stride,
+                                                               int64_t q_stride, int G, int64_t Nq, int k,
+                                                               float *__restrict__ out_dist,
                                                                int64_t *__restrict__ out_idx,
                                                                int64_t *__restrict__ out_keys)
 {
@@ -907,7 +908,7 @@ __global__ __launch_bounds__(256) void topk_merge_parts_kernel(const float *__re
             x[i] = KEY_MAX;
             if (gi < total) {
                 const int g = gi / k, off = gi - g * k;
-                const int64_t at = (int64_t)g * slot_stride + q * k + off;        // slot_stride >= Nq * k elements
+                const int64_t at = (int64_t)g * slot_stride + q * q_stride + off;  // [G, Nq, k]: slot_stride = Nq * k, q_stride = k
                 if constexpr (PACKED) {
                     const unsigned long long v = (unsigned long long)pi[at];
                     x[i] = v >= KEY_EMPTY ? KEY_MAX : v;
@@ -1452,20 +1453,243 @@ __global__ __launch_bounds__(256) void mfma_seed_kernel(const int64_t *__restric
     }
     thr[q] = t;
 }
+// ---- a handful of queries (one serving request) ---------------------------------------------------------------------
+constexpr int SMALLQ_CLIPS_MAX = 21;
+// The fused kernels put QUERIES on the lanes: with 1-8 queries a wave is 2-12 % full and the pass costs 0.55 ms however
+// little there is to score.  Here the lanes are clips and videos: every clip distance once (lane = clip, the canonical chain
+// against all NQ queries while the row streams past), then lane = video writes the keys of its moments -- the canonical sums
+// and IEEE quotients of the dense kernel -- and counts them against the rank keys; the top-k is two rounds of the pool
+// selection of topk_merge_parts_kernel over the key array (P ranges per query, then the P lists).  Exact like every f32 path.
+template <int NQ>
+__global__ __launch_bounds__(256) void smallq_dist_kernel(const float *__restrict__ Q, int Nq, const float *__restrict__ V,
+                                                          int total_clips, int D, float eps, float *__restrict__ dist)
+{
+    // D = 100 (the model's embedding width; other widths take the general loop below): the lane's whole row is requested at
+    // once (25 loads in flight), the queries sit in LDS and are read as broadcasts
+    __shared__ __attribute__((aligned(16))) float qs[NQ][FAST_D];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    float acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.0f;
+    if (D == FAST_D) {
+        for (int i = threadIdx.x; i < NQ * FAST_D; i += 256) qs[i / FAST_D][i % FAST_D] = Q[(int64_t)(i / FAST_D < Nq ? i / FAST_D : 0) * FAST_D + i % FAST_D];
+        float4 row[FAST_D / 4];
+        const float4 *v4 = reinterpret_cast<const float4 *>(V + (int64_t)(c < total_clips ? c : total_clips - 1) * FAST_D);
+#pragma unroll
+        for (int k4 = 0; k4 < FAST_D / 4; ++k4) row[k4] = v4[k4];
+        __syncthreads();
+#pragma unroll
+        for (int k4 = 0; k4 < FAST_D / 4; ++k4) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float4 qq = *reinterpret_cast<const float4 *>(&qs[q][4 * k4]);
+                float t = (row[k4].x - qq.x) + eps; acc[q] = __builtin_fmaf(t, t, acc[q]);
+                t = (row[k4].y - qq.y) + eps; acc[q] = __builtin_fmaf(t, t, acc[q]);
+                t = (row[k4].z - qq.z) + eps; acc[q] = __builtin_fmaf(t, t, acc[q]);
+                t = (row[k4].w - qq.w) + eps; acc[q] = __builtin_fmaf(t, t, acc[q]);
+            }
+        }
+    } else if (c < total_clips) {
+        const float *v = V + (int64_t)c * D;
+        for (int k = 0; k < D; ++k) {
+            const float vk = v[k];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float t = (vk - Q[(int64_t)(q < Nq ? q : 0) * D + k]) + eps;
+                acc[q] = __builtin_fmaf(t, t, acc[q]);
+            }
+        }
+    }
+    if (c >= total_clips) return;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        if (q < Nq) dist[(int64_t)q * total_clips + c] = __builtin_sqrtf(acc[q]);
+}
+
+// 16 videos per block, 16 threads per video (thread = the moments starting at clip s, s + 16, ...): canonical sums and
+// quotients, keys staged in LDS at their moment index and written out as one contiguous run (the videos' moments are
+// adjacent), rank counts reduced over the block
+constexpr int SQ_VIDEOS = 16, SQ_MOM = SMALLQ_CLIPS_MAX * (SMALLQ_CLIPS_MAX + 1) / 2;
+__global__ __launch_bounds__(256) void smallq_moments_kernel(const float *__restrict__ dist, int Nq, const int32_t *__restrict__ clip_off,
+                                                             const int64_t *__restrict__ mom_off, int Nv, int total_clips, int64_t id_base,
+                                                             unsigned long long *__restrict__ keys, int64_t Mpad, int num_rank,
+                                                             const float *__restrict__ rank_dist, const int64_t *__restrict__ rank_idx,
+                                                             int64_t *__restrict__ count_lt)
+{
+    __shared__ unsigned long long stage[SQ_VIDEOS * SQ_MOM];
+    __shared__ float ds[SQ_VIDEOS][SMALLQ_CLIPS_MAX + 3];
+    __shared__ int red[MAX_RANK][4];
+    const int q = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int vl = threadIdx.x >> 4, sl = threadIdx.x & 15;                   // video within the block, first start clip
+    const int v0 = blockIdx.x * SQ_VIDEOS, v = v0 + vl;
+    unsigned long long kstar[MAX_RANK] = {0, 0, 0, 0};
+    for (int r = 0; r < num_rank; ++r) kstar[r] = make_key(rank_dist[(int64_t)r * Nq + q], (unsigned)rank_idx[(int64_t)r * Nq + q]);
+    int nlt[MAX_RANK] = {0, 0, 0, 0};
+    const int vhi = v0 + SQ_VIDEOS < Nv ? v0 + SQ_VIDEOS : Nv;
+    const int64_t mb0 = mom_off[v0], mb1 = mom_off[vhi];                      // the block's run of moments
+    int n = 0, c0 = 0;
+    int64_t m0 = 0;
+    if (v < Nv) { c0 = clip_off[v]; n = clip_off[v + 1] - c0; m0 = mom_off[v]; }
+    for (int c = sl; c < n; c += 16) ds[vl][c] = dist[(int64_t)q * total_clips + c0 + c];
+    __syncthreads();
+    for (int s = sl; s < n; s += 16) {
+        float sum = 0.0f;
+        for (int e = s; e < n; ++e) {
+            const float de = ds[vl][e];
+            sum = e == s ? de : sum + de;
+            const float sc = sum / (float)(e - s + 1);
+            const int64_t m = m0 + moment_index(n, s, e);
+            const unsigned long long key = make_key(sc, (unsigned)(id_base + m));
+            stage[m - mb0] = key;
+#pragma unroll
+            for (int r = 0; r < MAX_RANK; ++r) nlt[r] += key < kstar[r] ? 1 : 0;     // kstar = 0 when unused
+        }
+    }
+    for (int r = 0; r < num_rank; ++r) {
+        int x = nlt[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        if (lane == 0) red[r][wv] = x;
+    }
+    __syncthreads();
+    if (keys)
+        for (int64_t i = threadIdx.x; i < mb1 - mb0; i += 256) keys[(int64_t)q * Mpad + mb0 + i] = stage[i];
+    if ((int)threadIdx.x < num_rank) {
+        const int r = threadIdx.x;
+        const long long t = (long long)red[r][0] + red[r][1] + red[r][2] + red[r][3];
+        if (t) atomicAdd(reinterpret_cast<unsigned long long *>(count_lt + (int64_t)r * Nq + q), (unsigned long long)t);
+    }
+}
+
+// One level of the selection tree over key lists [q][Pin][k]: wave (q, r) reads lists r*F .. r*F + F - 1 of query q as one
+// flat range -- the next round's keys requested before the current round is filtered -- keeps the k smallest in the LDS
+// pool of the merge kernels and writes them as list r of [q][Pout][k] (or, at the root, as the query's (dist, idx) rows).
+template <int KPL>
+__global__ __launch_bounds__(256) void topk_tree_kernel(const unsigned long long *__restrict__ in, int64_t Pin, int F, int64_t Pout,
+                                                        int64_t n_vq, int k, unsigned long long *__restrict__ out_keys,
+                                                        float *__restrict__ out_dist, int64_t *__restrict__ out_idx)
+{
+    constexpr int CAP = KPL * 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t vq = (int64_t)blockIdx.x * 4 + wv;
+    if (vq >= n_vq) return;
+    __shared__ unsigned long long pool_s[4][CAP];
+    unsigned long long *pool = pool_s[wv];
+    unsigned long long key[KPL];
+    unsigned long long thr = KEY_MAX;
+    int fill = 0;
+    auto lds_sync = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); };
+    auto sort_pool = [&](bool final_pass) {
+        lds_sync();
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) { const int e = i * 64 + lane; key[i] = e < fill ? pool[e] : KEY_MAX; }
+        wave_sort<KPL>(key, lane);
+        if (final_pass) return;
+        lds_sync();
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) { const int e = i * 64 + lane; if (e < k) pool[e] = key[i]; }
+        if (fill >= k) thr = key_at<KPL>(key, k - 1);
+        fill = fill < k ? fill : k;
+    };
+    const int64_t q = vq / Pout, r = vq - q * Pout, first = r * F;
+    const int64_t nl = Pin - first < F ? Pin - first : F;
+    const unsigned long long *src = in + (q * Pin + first) * k;
+    const int64_t total = nl * k;
+    // NB rounds of CAP keys are requested together and the next NB before these are filtered: a wave is alone with its
+    // range, so the memory latency it pays is per batch of requests, not per round
+    constexpr int NB = 4;
+    unsigned long long x[NB][KPL], xn[NB][KPL];
+    auto load = [&](unsigned long long (&dst)[NB][KPL], int64_t done) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                const int64_t gi = done + (b * KPL + i) * 64 + lane;
+                const unsigned long long vv = src[gi < total ? gi : total - 1];
+                dst[b][i] = (gi < total && vv < KEY_EMPTY) ? vv : KEY_MAX;
+            }
+    };
+    load(x, 0);
+    for (int64_t done = 0; done < total; done += NB * CAP) {
+        load(xn, done + NB * CAP);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                if (fill + 64 > CAP) sort_pool(false);
+                const bool pass = x[b][i] < thr;                 // KEY_MAX (empty) never passes
+                const unsigned long long m = __ballot(pass);
+                if (pass) pool[fill + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = x[b][i];
+                fill += __builtin_popcountll(m);
+            }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) x[b][i] = xn[b][i];
+    }
+    sort_pool(true);
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const int e = i * 64 + lane;
+        if (e < k) {
+            const bool ok = key[i] != KEY_MAX;
+            if (out_dist) {
+                out_dist[vq * k + e] = ok ? __uint_as_float((unsigned)(key[i] >> 32)) : __builtin_inff();
+                out_idx[vq * k + e] = ok ? (int64_t)(key[i] & 0xffffffffull) : -1;
+            } else {
+                out_keys[vq * k + e] = ok ? key[i] : KEY_EMPTY;
+            }
+        }
+    }
+}
+
+constexpr int SMALLQ_MAX = 8, SMALLQ_CLIPS = SMALLQ_CLIPS_MAX;
+struct SmallqWs { float *dist; unsigned long long *keys, *bufa, *bufb; int64_t Mpad, P0, P1; size_t total; };
+constexpr int SQ_F1 = 20, SQ_F = 32;        // lists of k per first-level range; fan-in of the later levels
+static SmallqWs carve_smallq(void *base, int64_t Nq, int total_clips, int k)
+{
+    SmallqWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *p = static_cast<char *>(base) + off; off += align_up(bytes, 256); return p; };
+    const int64_t Mb = (int64_t)total_clips * (SMALLQ_CLIPS + 1) / 2 + 1;            // >= total moments when every video has <= 21 clips
+    w.dist = reinterpret_cast<float *>(take((size_t)Nq * total_clips * 4));
+    if (k > 0) {
+        w.P0 = cdiv(Mb, k);                                                           // the key array as lists of k
+        w.Mpad = w.P0 * k;
+        w.P1 = cdiv(w.P0, SQ_F1);
+        w.keys = reinterpret_cast<unsigned long long *>(take((size_t)Nq * w.Mpad * 8));
+        w.bufa = reinterpret_cast<unsigned long long *>(take((size_t)Nq * w.P1 * k * 8));
+        w.bufb = reinterpret_cast<unsigned long long *>(take((size_t)Nq * cdiv(w.P1, SQ_F) * k * 8));
+    }
+    w.total = off;
+    return w;
+}
+static bool smallq_applicable(int64_t Nq, int Nv, int total_clips, int max_clips, int num_rank, int k)
+{
+    const int lim = opt_score_smallq() < SMALLQ_MAX ? opt_score_smallq() : SMALLQ_MAX;
+    return Nq > 0 && Nq <= lim && Nv > 0 && total_clips > 0 && max_clips <= SMALLQ_CLIPS && num_rank <= MAX_RANK && k <= 448;
+}
+static int run_smallq(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets, const int64_t *moment_offsets, int Nv,
+                      int total_clips, int D, float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
+                      const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, void *workspace, vfr_stream_t stream);
+
 }  // namespace vfr
 
 extern "C" {
+
 
 size_t vfr_score_topk_mfma_workspace_bytes(int64_t Nq, int Nv, int total_clips, int k)
 {
     if (Nq < 0 || Nv < 0 || k < 0 || total_clips < 0) return 0;
     const size_t a = vfr::carve_mfma(nullptr, Nq, Nv, total_clips, k).total, b = vfr_score_topk_workspace_bytes(Nq, Nv, k);
-    return a > b ? a : b;
+    const size_t c = Nq <= vfr::SMALLQ_MAX ? vfr::carve_smallq(nullptr, Nq, total_clips, k).total : 0;
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 int vfr_score_topk_mfma_prefilter(int64_t Nq, int Nv, int total_clips, int max_clips, int D, int num_rank, int k, int dtype)
 {
     dtype &= ~VFR_MFMA_BANK_READY;
+    if (dtype == VFR_MFMA_F32 && vfr::smallq_applicable(Nq, Nv, total_clips, max_clips, num_rank, k)) return 0;
     return Nq > 0 && k >= 0 && num_rank >= 0 && vfr::mfma_applicable(D, max_clips, num_rank, k, Nv, total_clips) &&
            vfr::mfma_worthwhile(Nv, dtype) && vfr::opt_score_fast();
 }
@@ -1482,6 +1706,16 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
     VFR_REQUIRE(workspace && workspace_bytes >= vfr_score_topk_mfma_workspace_bytes(Nq, Nv, total_clips, k), VFR_EWORKSPACE,
                 "vfr_score_topk_mfma: workspace %zu < %zu bytes", workspace_bytes,
                 vfr_score_topk_mfma_workspace_bytes(Nq, Nv, total_clips, k));
+    if (dtype == VFR_MFMA_F32 && Q && V && clip_offsets && moment_offsets && k >= 0 && num_rank >= 0 &&
+        vfr::smallq_applicable(Nq, Nv, total_clips, max_clips, num_rank, k)) {
+        // a handful of queries: lanes = clips / videos instead of queries (exact; thr_seed is only an accelerator)
+        VFR_REQUIRE(k == 0 || (out_dist && out_idx), VFR_EINVAL, "vfr_score_topk_mfma: k > 0 needs out_dist/out_idx");
+        VFR_REQUIRE(num_rank == 0 || (rank_dist && rank_idx && count_lt), VFR_EINVAL,
+                    "vfr_score_topk_mfma: num_rank > 0 needs rank_dist, rank_idx and count_lt");
+        VFR_REQUIRE(id_base >= 0 && D > 0, VFR_EINVAL, "vfr_score_topk_mfma: bad id_base / D");
+        return vfr::run_smallq(Q, Nq, V, clip_offsets, moment_offsets, Nv, total_clips, D, eps, id_base, k, out_dist, out_idx, num_rank,
+                               rank_dist, rank_idx, count_lt, workspace, stream);
+    }
     if (!(Q && V && clip_offsets && moment_offsets && Nq > 0 && k >= 0 && num_rank >= 0) ||
         !vfr::mfma_applicable(D, max_clips, num_rank, k, Nv, total_clips) || !vfr::mfma_worthwhile(Nv, dtype) || !vfr::opt_score_fast()) {
         // shapes the pre-filter is not built for: the exact kernels give the same results in f32 mode
@@ -1616,14 +1850,15 @@ int vfr_score_topk_mfma_stats(const void *workspace, int64_t Nq, int Nv, int tot
 }
 
 static int launch_merge_parts(const float *pd, const int64_t *pi, bool packed, int G, int64_t Nq, int k, float *od,
-                              int64_t *oi, int64_t *okeys, vfr_stream_t stream, int64_t slot_stride = 0)
+                              int64_t *oi, int64_t *okeys, vfr_stream_t stream, int64_t slot_stride = 0, int64_t q_stride = 0)
 {
     if (slot_stride == 0) slot_stride = Nq * k;
+    if (q_stride == 0) q_stride = k;
     dim3 grid((unsigned)vfr::cdiv(Nq, 4)), block(256);
     const int kpl = vfr::kpl_for(k);
     vfr::ProfScope prof(vfr::SITE_EXCHANGE, vfr::as_stream(stream));
 #define VFR_MERGE(KPL, PACKED) hipLaunchKernelGGL((vfr::topk_merge_parts_kernel<KPL, PACKED>), grid, block, 0, \
-                                                  vfr::as_stream(stream), pd, pi, slot_stride, G, Nq, k, od, oi, okeys)
+                                                  vfr::as_stream(stream), pd, pi, slot_stride, q_stride, G, Nq, k, od, oi, okeys)
     if (packed) { if (kpl == 4) VFR_MERGE(4, true); else VFR_MERGE(8, true); }
     else        { if (kpl == 4) VFR_MERGE(4, false); else VFR_MERGE(8, false); }
 #undef VFR_MERGE
@@ -1707,3 +1942,47 @@ int vfr_gt_labels_u8(const int32_t *times, const int32_t *nannot, const int32_t 
 }
 
 }  // extern "C"
+
+namespace vfr {
+static int run_smallq(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets, const int64_t *moment_offsets, int Nv,
+                      int total_clips, int D, float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
+                      const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, void *workspace, vfr_stream_t stream)
+{
+    hipStream_t st = as_stream(stream);
+    SmallqWs w = carve_smallq(workspace, Nq, total_clips, k);
+    {
+        ProfScope prof(SITE_SCORE_FUSED, st);
+        const dim3 grid((unsigned)cdiv(total_clips, 256));
+        if (Nq == 1)      hipLaunchKernelGGL(smallq_dist_kernel<1>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
+        else if (Nq == 2) hipLaunchKernelGGL(smallq_dist_kernel<2>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
+        else if (Nq <= 4) hipLaunchKernelGGL(smallq_dist_kernel<4>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
+        else              hipLaunchKernelGGL(smallq_dist_kernel<8>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
+        // unwritten key slots (the padding past the last moment) must read as empty: any value >= KEY_EMPTY does
+        if (k > 0 && hipMemsetAsync(w.keys, 0xFF, (size_t)Nq * w.Mpad * 8, st) != hipSuccess)
+            return fail(VFR_EHIP, "vfr_score_topk_mfma: hipMemsetAsync failed");
+        hipLaunchKernelGGL(smallq_moments_kernel, dim3((unsigned)cdiv(Nv, SQ_VIDEOS), (unsigned)Nq), dim3(256), 0, st, w.dist, (int)Nq, clip_offsets,
+                           moment_offsets, Nv, total_clips, id_base, k > 0 ? w.keys : nullptr, w.Mpad, num_rank, rank_dist, rank_idx, count_lt);
+        VFR_CHECK_LAUNCH("smallq kernels");
+    }
+    if (k == 0) return VFR_OK;
+    // selection tree: ranges of SQ_F1 lists of k keys -> lists of k, then SQ_F lists at a time until one list per query is left
+    ProfScope prof(SITE_TOPK_MERGE, st);
+    const int kpl = kpl_for(k);
+    const unsigned long long *in = w.keys;
+    int64_t Pin = w.P0;
+    int F = SQ_F1;
+    unsigned long long *bufs[2] = {w.bufa, w.bufb};
+    for (int level = 0;; ++level) {
+        const int64_t Pout = cdiv(Pin, F), n_vq = Nq * Pout;
+        const bool root = Pout == 1;
+        unsigned long long *out = root ? nullptr : bufs[level & 1];
+        const dim3 grid((unsigned)cdiv(n_vq, 4));
+        if (kpl == 4) hipLaunchKernelGGL(topk_tree_kernel<4>, grid, dim3(256), 0, st, in, Pin, F, Pout, n_vq, k, out, root ? out_dist : nullptr, root ? out_idx : nullptr);
+        else          hipLaunchKernelGGL(topk_tree_kernel<8>, grid, dim3(256), 0, st, in, Pin, F, Pout, n_vq, k, out, root ? out_dist : nullptr, root ? out_idx : nullptr);
+        if (root) break;
+        in = out; Pin = Pout; F = Pin <= 2 * SQ_F ? (int)Pin : SQ_F;
+    }
+    VFR_CHECK_LAUNCH("topk_tree_kernel");
+    return VFR_OK;
+}
+}  // namespace vfr

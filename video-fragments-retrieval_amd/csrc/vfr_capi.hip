@@ -18,6 +18,7 @@ static std::atomic<int> g_opt_gemm_small{0};       // small dense GEMMs: 0 = 32-
 static std::atomic<int> g_opt_lstm_xcd{1};         // 1: XCD-aware workgroup order of the fused LSTM step; 0: launch order (cross-check)
 static std::atomic<int> g_opt_lstm_skip0{1};       // 1: the first LSTM step skips its recurrent segment (h_0 = 0); 0: runs it (cross-check)
 static std::atomic<int> g_opt_score_tasks{0};      // > 0: wave-tasks the scorer's plan aims for (experiment; 0 = automatic)
+static std::atomic<int> g_opt_score_smallq{8};     // batches of up to this many queries (<= 8) are scored with lanes = clips / videos (vfr_score_topk_mfma, f32); 0: never
 static std::atomic<int> g_opt_score_pre_b{0};      // > 0: videos in ladder stage B (experiment; 0 = Nv/16 capped at 640)
 static std::atomic<int> g_opt_gemm_pp{0};          // 1: ping-pong schedule (512-thread workgroups, two tile groups) for the large MFMA GEMMs (experiment)
 static std::atomic<int> g_opt_mfma_min{128};        // banks of fewer videos go to the exact scorer (the pre-filter's fixed launches cost more); tests set 0
@@ -27,7 +28,7 @@ static std::atomic<int> g_opt_lstm_tile{0};        // 0: by grid size, 1: 64-row
 struct Opt { const char *name; std::atomic<int> *v; };
 static const Opt g_opts[] = {
     {"gemm", &g_opt_gemm}, {"profile", &g_opt_profile}, {"score_fast", &g_opt_score_fast}, {"score_split", &g_opt_score_split},
-    {"score_pre_b", &g_opt_score_pre_b}, {"score_tasks", &g_opt_score_tasks}, {"lstm_skip0", &g_opt_lstm_skip0},
+    {"score_pre_b", &g_opt_score_pre_b}, {"score_smallq", &g_opt_score_smallq}, {"score_tasks", &g_opt_score_tasks}, {"lstm_skip0", &g_opt_lstm_skip0},
     {"lstm_xcd", &g_opt_lstm_xcd}, {"gemm_small", &g_opt_gemm_small}, {"lstm_tile", &g_opt_lstm_tile}, {"gemm_pp", &g_opt_gemm_pp}, {"score_mfma_min", &g_opt_mfma_min}, {"lstm_small", &g_opt_lstm_small},
 };
 
@@ -78,6 +79,7 @@ int opt_gemm() { return g_opt_gemm; }
 int opt_score_fast() { return g_opt_score_fast; }
 int opt_score_split() { return g_opt_score_split; }
 int opt_score_pre_b() { return g_opt_score_pre_b; }
+int opt_score_smallq() { return g_opt_score_smallq; }
 int opt_score_tasks() { return g_opt_score_tasks; }
 int opt_lstm_skip0() { return g_opt_lstm_skip0; }
 int opt_lstm_xcd() { return g_opt_lstm_xcd; }
