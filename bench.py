@@ -53,7 +53,7 @@ def parse():
                     help="vfr_set_option passthrough for parameter sweeps (results must not change: compare the checksums)")
     ap.add_argument("--host-feed", action="store_true",
                     help="also time the pass with the pooled features in pinned HOST memory (PCIe-inclusive; extra field, never `value`)")
-    ap.add_argument("--cpu-sample", default="1024x4000", help="queries x videos for the CPU baseline sample")
+    ap.add_argument("--cpu-sample", default="1024x8000", help="queries x videos for the CPU baseline sample")
     return ap.parse_args()
 
 
