@@ -8,6 +8,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import vfr_amd  # noqa
 from vfr_amd import _vfr, engine, models, synth
 
+for _item in filter(None, __import__("os").environ.get("VFR_OPTS", "").split(",")):     # e.g. VFR_OPTS=lstm_persist=0
+    _vfr.set_option(_item.split("=")[0], int(_item.split("=")[1]))
 Nv, n, F, k = 10000, 21, 4096, 100
 dev = torch.device("cuda:0")
 counts = synth.clip_counts(Nv, n, seed=123)

@@ -151,7 +151,9 @@ __global__ __launch_bounds__(256) void unsort_rows_kernel(const float *__restric
 // itself -- acc = fma(x_k, W_ih[c][k], acc) over E, then fma(h_k, W_hh[c][k], acc) over H -- for all RB rows: [x_t | h]
 // of the rows is staged in LDS once and read back as broadcasts (scalar loads cannot be kept in flight: every chunk paid
 // their latency), the weights come from a chunk-major copy [(E + H) / 4][4H][4] made once per call (one coalesced 16-byte
-// load per lane and 4 k's), fetched PF chunks ahead.  17 us per step at one query, 25 at two (default limit), 38 at four.  A wave = 4 gates x 16 units, so the four pre-activations of a
+// load per lane and 4 k's), fetched PF chunks ahead.  16 us per step at one query, 25 at two (default limit), 38 at four.  (hipcc drains all
+// outstanding loads at the head of the chunk loop -- one latency per 32 chunks; a single launch for all T steps with an
+// arrival counter between steps was built and measured: 20 us per step, slower than the launches, and removed.)  A wave = 4 gates x 16 units, so the four pre-activations of a
 // unit meet through 1 KB of LDS and 16 lanes finish the cells.  Same chains, same bits (test: lstm_small = 0 vs 4).
 struct SmallLstm {
     const float *X;                       // [B*T, E] embedded tokens
@@ -226,7 +228,10 @@ __global__ __launch_bounds__(64) void lstm_step_small_kernel(SmallLstm a)
     int base = 0;
     for (; base + PF <= nchunk; base += PF) {
 #pragma unroll
-        for (int j = 0; j < PF; ++j) { chain(j, j % XF); fetch(j, base + j + PF); xfetch(j % XF, base + j + XF); }
+        for (int j = 0; j < PF; ++j) {
+            chain(j, j % XF); fetch(j, base + j + PF); xfetch(j % XF, base + j + XF);
+            __builtin_amdgcn_sched_barrier(0);          // keep every refill right behind its chunk (hipcc sinks them to the loop end)
+        }
     }
 #pragma unroll
     for (int j = 0; j < PF; ++j)
