@@ -459,7 +459,40 @@ def extras(args, dev, model, seg, ctx, clip_off, tokens, make_shard, ranks_of, o
                      "finite": bool(torch.isfinite(feat).all())}
     except RuntimeError as e:                                   # e.g. out of memory on a shared device: report, do not hide
         ex["vgg"] = {"error": str(e)[:200]}
+    ex["cpu_baseline_loop"] = cpu_loop_baseline(emb, clip_off, Q, counts_all)
     return ex
+
+
+def cpu_loop_baseline(emb, clip_off, Q, counts_all, n_queries=10, n_videos=1000):
+    """the scoring loop with the reference's own structure (model/evaluate.py:42-80) on the host --
+    per query, per video one F.pairwise_distance over the video's clips, per moment index_select -> mean -> .item(), then
+    np.argsort over all moments -- on the embeddings of the first n_videos videos, single thread like the reference's loop.
+    A stated subsample, extrapolated as a rate.  (`cpu_baseline` above is the multi-threaded C oracle, the stronger baseline.)"""
+    import torch.nn.functional as F
+    from vfr_amd.utils import generate_moments
+    off = clip_off[:n_videos + 1].cpu().numpy()
+    V = emb[:int(off[-1])].float().cpu()
+    Qc = Q[:n_queries].float().cpu()
+    moments = {int(n): [torch.arange(s, e + 1) for s, e in generate_moments(int(n))] for n in set(int(x) for x in counts_all[:n_videos])}
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        t0 = time.perf_counter()
+        for q in range(Qc.shape[0]):
+            distances = []
+            for v in range(n_videos):
+                vis = V[int(off[v]):int(off[v + 1])]
+                d = F.pairwise_distance(vis, Qc[q:q + 1].expand_as(vis))
+                for idx in moments[vis.shape[0]]:
+                    distances.append(d.index_select(0, idx).mean().item())
+            np.argsort(np.asarray(distances))
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(threads)
+    return {"value": Qc.shape[0] * n_videos / dt, "unit": "scorings/s", "cores": 1, "kind": "port",
+            "sample": f"{Qc.shape[0]} queries x {n_videos} videos of the bench corpus (embeddings given), the reference's loop structure "
+                      f"(pairwise_distance per video, index_select/mean/.item() per moment, np.argsort per query) in {dt:.1f} s",
+            "host": {"cpu_count": os.cpu_count(), "torch_threads": threads, "torch": torch.__version__}}
 
 
 if __name__ == "__main__":
