@@ -119,16 +119,31 @@ __global__ __launch_bounds__(1024) void segment_pool_norm_video_kernel(const flo
     const float4 *src = reinterpret_cast<const float4 *>(frames) + fbeg * nchunk + (live ? chunk : 0);
     float4 call = make_float4(0.f, 0.f, 0.f, 0.f), cseg = call;
     int in_seg = 0;
-    for (int64_t t = fbeg; t < fend; ++t, src += nchunk) {
-        const float4 x = live ? *src : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t == fbeg) call = x;
-        else if (mode) { call.x = fmaxf(call.x, x.x); call.y = fmaxf(call.y, x.y); call.z = fmaxf(call.z, x.z); call.w = fmaxf(call.w, x.w); }
-        else { call.x = call.x + x.x; call.y = call.y + x.y; call.z = call.z + x.z; call.w = call.w + x.w; }
-        if (in_seg == 0) cseg = x;
-        else if (mode) { cseg.x = fmaxf(cseg.x, x.x); cseg.y = fmaxf(cseg.y, x.y); cseg.z = fmaxf(cseg.z, x.z); cseg.w = fmaxf(cseg.w, x.w); }
-        else { cseg.x = cseg.x + x.x; cseg.y = cseg.y + x.y; cseg.z = cseg.z + x.z; cseg.w = cseg.w + x.w; }
-        ++in_seg;
-        if (in_seg == seg_len || t + 1 == fend) {       // segment complete (uniform across the workgroup)
+    // frames of a segment are requested U at a time (one 16-byte load per thread and frame: with a single load in flight per
+    // wave the kernel ran at 4.1-4.4 TB/s, now 4.2-4.5; the accumulation stays in frame order.  A barrier-free two-pass form --
+    // streaming pools, then a row-normalisation pass -- was measured slower: 3.8-4.0 TB/s)
+    constexpr int U = 5;
+    for (int64_t t = fbeg; t < fend;) {
+        const int64_t left = seg_len - in_seg, seg_end = t + left < fend ? t + left : fend;
+        while (t < seg_end) {
+            const int nb = seg_end - t < U ? (int)(seg_end - t) : U;
+            float4 x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = live ? src[(int64_t)(u < nb ? u : nb - 1) * nchunk] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (u < nb) {
+                    if (t + u == fbeg) call = x[u];
+                    else if (mode) { call.x = fmaxf(call.x, x[u].x); call.y = fmaxf(call.y, x[u].y); call.z = fmaxf(call.z, x[u].z); call.w = fmaxf(call.w, x[u].w); }
+                    else { call.x = call.x + x[u].x; call.y = call.y + x[u].y; call.z = call.z + x[u].z; call.w = call.w + x[u].w; }
+                    if (in_seg + u == 0) cseg = x[u];
+                    else if (mode) { cseg.x = fmaxf(cseg.x, x[u].x); cseg.y = fmaxf(cseg.y, x[u].y); cseg.z = fmaxf(cseg.z, x[u].z); cseg.w = fmaxf(cseg.w, x[u].w); }
+                    else { cseg.x = cseg.x + x[u].x; cseg.y = cseg.y + x[u].y; cseg.z = cseg.z + x[u].z; cseg.w = cseg.w + x[u].w; }
+                }
+            }
+            t += nb; src += (int64_t)nb * nchunk; in_seg += nb;
+        }
+        {                                               // segment complete (uniform across the workgroup)
             if (!mode) { const float c = (float)in_seg; cseg.x = cseg.x / c; cseg.y = cseg.y / c; cseg.z = cseg.z / c; cseg.w = cseg.w / c; }
             const float nrm = row_norm_tree64(cseg, chunk, nchunk, sh, &sh_norm);
             if (live) {
