@@ -85,6 +85,28 @@ __device__ __forceinline__ void video_distances(const float *__restrict__ V, int
     }
 }
 
+// value of lane (lane ^ STRIDE): within a row of 16 lanes through the DPP data path (one or two v_mov_b32_dpp per dword, a
+// few cycles), across rows through ds_bpermute (an LDS round trip).  26 of the 33 cross-lane stages of the 256-key sort
+// have STRIDE <= 8, and the stages depend on each other: the round trips were the sort's time.
+template <int STRIDE>
+__device__ __forceinline__ unsigned xor_lane_u32(unsigned x)
+{
+    if constexpr (STRIDE == 1) return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+    else if constexpr (STRIDE == 2) return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false); // quad_perm [2,3,0,1]
+    else if constexpr (STRIDE == 4) {
+        const int t = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xF, 0x5, false);       // row_shl:4 into banks 0, 2 (lane <- lane + 4)
+        return (unsigned)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xF, 0xA, false);          // row_shr:4 into banks 1, 3 (lane <- lane - 4)
+    } else if constexpr (STRIDE == 8) {
+        const int t = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x108, 0xF, 0x3, false);       // row_shl:8 into banks 0, 1
+        return (unsigned)__builtin_amdgcn_update_dpp(t, (int)x, 0x118, 0xF, 0xC, false);          // row_shr:8 into banks 2, 3
+    } else return (unsigned)__shfl_xor((int)x, STRIDE, 64);
+}
+template <int STRIDE>
+__device__ __forceinline__ unsigned long long xor_lane_u64(unsigned long long x)
+{
+    return ((unsigned long long)xor_lane_u32<STRIDE>((unsigned)(x >> 32)) << 32) | xor_lane_u32<STRIDE>((unsigned)x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // wave-cooperative bitonic sort of KPL*64 keys, element e = i*64 + lane, ascending
 // ------------------------------------------------------------------------------------------------
@@ -116,10 +138,13 @@ __device__ __forceinline__ void wave_sort(unsigned long long (&key)[KPL], int la
                     if (size >= CAP) asc = true;
                     else if (size >= 64) asc = (i & (size >> 6)) == 0;
                     else asc = (lane & size) == 0;
-                    unsigned long long other = __shfl_xor(key[i], stride, 64);
-                    unsigned long long mn = key[i] < other ? key[i] : other;
-                    unsigned long long mx = key[i] < other ? other : key[i];
-                    key[i] = (lower == asc) ? mn : mx;
+                    // the lane keeps its key when (it wants the smaller one) == (its key is the smaller one): one 64-bit
+                    // compare and two selects (min / max / select took ten vector instructions per key and stage)
+                    const unsigned long long other = stride == 1 ? xor_lane_u64<1>(key[i]) : stride == 2 ? xor_lane_u64<2>(key[i])
+                                                   : stride == 4 ? xor_lane_u64<4>(key[i]) : stride == 8 ? xor_lane_u64<8>(key[i])
+                                                   : stride == 16 ? xor_lane_u64<16>(key[i]) : xor_lane_u64<32>(key[i]);
+                    const bool keep = (lower == asc) == (key[i] < other);
+                    key[i] = keep ? key[i] : other;
                 }
             }
         }
@@ -812,9 +837,21 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
     };
 
     int total = 0;
-    for (int base = 0; base < num_chunks; base += 64) {
+    // all chunk counts are requested before the first is used: with few queries in flight (a serving request runs 1024 chunks
+    // for its one query group) sixteen dependent load latencies were most of this kernel's time
+    constexpr int NSC = MERGE_MAX_CHUNKS / 64;
+    int cc[NSC];
+#pragma unroll
+    for (int j = 0; j < NSC; ++j) {
+        const int ch = j * 64 + lane;
+        cc[j] = ch < num_chunks ? buf_cnt[((size_t)ch * num_groups + group) * 64 + ql] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < NSC; ++j) {
+        const int base = j * 64;
+        if (base >= num_chunks) break;
         const int ch = base + lane;
-        const int c = ch < num_chunks ? buf_cnt[((size_t)ch * num_groups + group) * 64 + ql] : 0;
+        const int c = cc[j];
         int incl = c;                                   // inclusive wave scan
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
