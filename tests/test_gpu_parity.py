@@ -330,6 +330,19 @@ TALL_VGG = [72, "M", 8, "M", 8, "M", 8, "M", 8, "M"]
 
 
 @pytest.mark.gpu
+def test_frames_normalize_equals_reference_getitem(vfr, golden):
+    """a1 against the reference itself: vfr_frames_normalize_f32 on the frames the product's selection keeps == the tensor the
+    unmodified DiDeMoDataset.__getitem__ returned (fixture G11, get_rgb_features.py:37-78), bit for bit."""
+    from test_host_logic import g11_norm_input
+    from vfr_amd import features
+    g = golden("g11_frame_front_end.npz")
+    fr = g11_norm_input()
+    idx = features.sample_frames(150, 30.0, 1)
+    assert idx.tolist() == g["idx_3"].tolist()
+    assert same(vfr.frames_normalize(dev(fr[idx])), g["norm_frames"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg,T", [(WIDE_VGG, 5), (TALL_VGG, 17)])
 def test_vgg_conv_launch_forms_bit_exact(vfr, oracle, cfg, T):
     frames = synth.frames_u8(T, 64, 48, seed=4)
@@ -340,10 +353,11 @@ def test_vgg_conv_launch_forms_bit_exact(vfr, oracle, cfg, T):
 
 
 # ---------------------------------------------------------------------------------------------
-def test_full_size_properties(vfr, score_mode):
-    """BASELINE config 1 shape (10k videos x 21 clips) where the oracle is too slow: size-independent
-    properties -- shard-and-merge == unsharded, top-k sorted with unique ids, rank count consistent with the
-    list, sampled rows == dense kernel."""
+def test_full_size_properties(vfr, oracle, score_mode):
+    """BASELINE config 1 shape (10k videos x 21 clips): size-independent properties -- shard-and-merge == unsharded,
+    top-k sorted with unique ids, rank count consistent with the list, sampled rows == dense kernel -- and, for four
+    queries of a 5000-query batch, the fused pass over the FULL corpus against the CPU oracle (top-100 ids, distances and
+    both rank counts, bit for bit)."""
     torch.manual_seed(0)
     nv, n, nq, k = 10000, 21, 256, 100
     V = torch.randn(nv * n, 100, device=DEV)
@@ -378,6 +392,13 @@ def test_full_size_properties(vfr, score_mode):
     db, ib, cb = vfr.score_topk(Qb, bank, k, full_rd.contiguous(), full_ri.contiguous())
     assert torch.equal(ib[sel], order) and torch.equal(db[sel], dense.gather(1, order))
     assert cb[0, sel].tolist() == [36] * 4 and cb[1, sel].tolist() == [90] * 4
+    # the same four queries through the CPU oracle over all 10 000 videos (model/evaluate.py:49-80 restated)
+    Vh, offh, Qh = V.cpu().numpy(), off.cpu().numpy(), Qb[sel].cpu().numpy()
+    od, oi = oracle.score_topk(Qh, Vh, offh, k)
+    assert np.array_equal(ib[sel].cpu().numpy(), oi) and np.array_equal(db[sel].cpu().numpy(), od)
+    for t, pos in enumerate((36, 90)):
+        oc = oracle.rank_of(Qh, Vh, offh, od[:, pos].copy(), oi[:, pos].copy())
+        assert oc.tolist() == [pos] * 4 and cb[t, sel].tolist() == oc.tolist()
     assert torch.equal(ib[:nq], i) and torch.equal(db[:nq], d)                  # a query's result does not depend on its batch
     # spot-check against the dense kernel on the videos that own the winners
     top_vid = (i[:8, 0] // M).cpu().numpy()
@@ -883,9 +904,11 @@ def test_bf16_scoring_tolerance_on_reference_embeddings(vfr, oracle, golden, tag
 
 
 @pytest.mark.gpu
-def test_bf16_scoring_tolerance_full_corpus(vfr):
+def test_bf16_scoring_tolerance_full_corpus(vfr, oracle):
     """Config 5 at BASELINE size (10k videos x 21 clips, 256-query batch): rank@1 agreement >= 0.99, top-10 overlap >= 0.98,
-    top-100 overlap >= 0.95 against the fp32 path, rank counts within 1 % of the 2.31 M moments."""
+    top-100 overlap >= 0.95 against the fp32 path, rank counts within 1 % of the 2.31 M moments.  The fp32 side of the
+    comparison is itself checked against the CPU oracle on four of the queries over the full corpus (bit-identical), and
+    the bf16 list of those queries against the oracle's directly."""
     torch.manual_seed(1)
     nv, n, nq, k = 10000, 21, 256, 100
     V = torch.randn(nv * n, 100, device=DEV) * 0.1
@@ -902,6 +925,15 @@ def test_bf16_scoring_tolerance_full_corpus(vfr):
     assert float((i0[:, :, None] == i1[:, None, :]).any(-1).float().mean()) >= 0.95
     assert bool((c0[0] == 40).all())
     assert float((c0 - c1).abs().max()) <= 0.01 * nv * n * (n + 1) / 2
+    sel = [0, 77, 128, 255]
+    Vh, offh, Qh = V.cpu().numpy(), off.cpu().numpy(), Q[sel].cpu().numpy()
+    od, oi = oracle.score_topk(Qh, Vh, offh, k)
+    assert np.array_equal(i0[sel].cpu().numpy(), oi) and np.array_equal(d0[sel].cpu().numpy(), od)
+    oc = oracle.rank_of(Qh, Vh, offh, od[:, 40].copy(), oi[:, 40].copy())
+    assert oc.tolist() == [40] * 4 and c0[0, sel].tolist() == [40] * 4
+    bi = i1[sel].cpu().numpy()
+    assert (bi[:, 0] == oi[:, 0]).mean() >= 0.75                                    # rank@1 vs the CPU reference path
+    assert np.mean([len(set(bi[q, :10]) & set(oi[q, :10])) / 10 for q in range(4)]) >= 0.9
 
 
 @pytest.mark.gpu

@@ -11,6 +11,7 @@ import torch
 
 from helpers import MemoryDataset, make_model, problem
 from vfr_amd import data as vdata
+from vfr_amd import synth
 from vfr_amd import evaluate as vevaluate
 from vfr_amd import evaluate_single as vsingle
 from vfr_amd import utils as vutils
@@ -348,6 +349,35 @@ def test_frame_sampling_matches_reference_arithmetic(oracle):
         got = features.sample_frames(nf, fps, nseg)
         assert got.tolist() == oracle.frame_sample_indices(nf, fps, nseg), (nf, fps, nseg)
         assert got.dtype == np.int64 and (np.diff(got) >= 0).all() and got.max() < max(nf, 1)
+
+
+def g11_norm_input():
+    """The seeded uint8 frames the G11 normalisation case was generated from (tools/gen_golden.py::g11_frame_front_end)."""
+    fr = synth.frames_u8(150, 16, 16, seed=11)
+    ramp = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    fr[0, :, :, 0], fr[0, :, :, 1], fr[0, :, :, 2] = ramp, ramp[::-1], ramp.T
+    return fr
+
+
+def test_frame_front_end_matches_reference_getitem(golden, oracle):
+    """a1 + f4 pinned to the reference ITSELF (fixture G11 = the unmodified DiDeMoDataset.__getitem__,
+    get_rgb_features.py:37-78, fed by a stubbed read_video): selected frame indices for 28 (frames, fps, segments) cases --
+    full clips, short last segments, one-segment clips, one frame, an empty read -- from both the product's vectorised
+    selection and the oracle's restatement; the oracle's normalisation == the reference's tensor bit for bit."""
+    from vfr_amd import features
+    g = golden("g11_frame_front_end.npz")
+    cases = g["cases"]
+    assert len(cases) >= 20
+    for i, (nf, fps, nseg) in enumerate(cases):
+        want = g[f"idx_{i}"].tolist()
+        assert features.sample_frames(int(nf), float(fps), int(nseg)).tolist() == want, (i, nf, fps, nseg)
+        assert list(oracle.frame_sample_indices(int(nf), float(fps), int(nseg))) == want, (i, nf, fps, nseg)
+    assert [len(g[f"idx_{i}"]) for i in range(3)] == [150, 138, 125]            # SURVEY 3.1's counts
+    fr = g11_norm_input()
+    idx = features.sample_frames(150, 30.0, 1)
+    want = g["norm_frames"]
+    got = oracle.frames_normalize(fr[idx])
+    assert got.shape == want.shape and np.array_equal(got, want)
 
 
 def test_extract_dataset_resume_and_missed_bookkeeping(tmp_path, monkeypatch):

@@ -11,7 +11,8 @@ OUTPUTS plus the recipe parameters; tests regenerate the inputs from the same se
 Fixtures:  G1 encoders, G2 scoring + both evaluate() dicts (n=6, n=21, ragged 5/6),
 G3 generate_moments / get_iou, G4 load_video_features pooling, G5 tokeniser + WordIndexer, G6 validate_epoch,
 G7 ranking loss, G8 evaluate() with the 'chance' baseline, G9 one full-size VGG-19 frame through torch.nn modules,
-G10 encoder gradients (loss.backward() through CALModel).
+G10 encoder gradients (loss.backward() through CALModel), G11 DiDeMoDataset.__getitem__ of get_rgb_features.py (frame selection +
+normalisation) with torchvision.io.read_video stubbed by a seeded frame generator.
 """
 import json
 import random
@@ -386,7 +387,69 @@ def g10_encoder_grads():
     print("G10", sorted(k for k in out if "grad" in k))
 
 
+G11_CASES = [  # (decoded frames, fps, num_segments)
+    (900, 30.0, 6), (819, 30.0, 6), (750, 30.0, 5), (150, 30.0, 1), (60, 30.0, 1), (1, 30.0, 1), (0, 30.0, 6),
+    (899, 29.97, 6), (720, 24.0, 6), (719, 23.976, 6), (625, 25.0, 5), (610, 25.0, 5), (450, 15.0, 6), (375, 12.5, 6),
+    (1798, 59.94, 6), (1500, 59.94, 6), (301, 30.0, 2), (299, 30.0, 2), (164, 30.0, 2), (151, 30.0, 2), (436, 29.97, 3),
+    (449, 29.97, 3), (30, 30.0, 6), (866, 30.0, 6), (884, 30.0, 6), (885, 30.0, 6), (120, 24.0, 1), (132, 24.0, 1),
+]
+
+
+def g11_frame_front_end():
+    """a1 + f4 front half: the UNMODIFIED ``DiDeMoDataset.__getitem__`` (get_rgb_features.py:37-78).  torchvision is absent
+    from this image; the module only needs ``torchvision.io.read_video`` at call time, so a stub returns seeded uint8
+    frames and ``{'video_fps': fps}`` (decode is codec I/O, outside the path).  Index cases: 1x1 frames whose red / green
+    bytes spell the frame number, so the selected indices are read back from the reference's own normalised output.
+    Normalisation case: 16x16 frames carrying every byte value in every channel; the full [T_sel, 3, 16, 16] tensor is kept."""
+    table = {}
+
+    def read_video(filename, pts_unit="sec", end_pts=None, **kw):
+        frames, fps = table[Path(filename).stem]
+        return torch.from_numpy(frames), torch.empty(0), {"video_fps": fps}
+
+    tv = types.ModuleType("torchvision")
+    tv.io = types.ModuleType("torchvision.io")
+    tv.io.read_video = read_video
+    sys.modules["torchvision"], sys.modules["torchvision.io"] = tv, tv.io
+    sys.path.insert(0, str(REF))
+    import get_rgb_features as ref_rgb  # noqa: E402  (reference; its __main__ block does not run on import)
+
+    mean = np.array([0.485, 0.456, 0.406]); std = np.array([0.229, 0.224, 0.225])
+    info, out = [], {"cases": np.asarray(G11_CASES, np.float64)}
+    for i, (nf, fps, nseg) in enumerate(G11_CASES):
+        fr = np.zeros((nf, 1, 1, 3), np.uint8)
+        fr[:, 0, 0, 0] = np.arange(nf) % 256
+        fr[:, 0, 0, 1] = np.arange(nf) // 256
+        table[f"case{i}"] = (fr, fps)
+        info.append(dict(video=f"case{i}", num_segments=nseg))
+    ds = ref_rgb.DiDeMoDataset(info, dataset_dir="unused")
+    for i, (nf, fps, nseg) in enumerate(G11_CASES):
+        item = ds[i]
+        x = item["frames"].numpy()
+        if nf == 0:
+            assert x.shape == (0, 1, 1, 3)                                  # the unreadable-file branch (:75-78)
+            out[f"idx_{i}"] = np.zeros(0, np.int64)
+            continue
+        b = np.rint((x[:, :, 0, 0].astype(np.float64) * std + mean) * 255.0).astype(np.int64)
+        out[f"idx_{i}"] = b[:, 0] + 256 * b[:, 1]
+    # normalisation: every byte value in every channel
+    fr = synth.frames_u8(150, 16, 16, seed=11)
+    fr[0, :, :, 0] = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    fr[0, :, :, 1] = np.arange(256, dtype=np.uint8).reshape(16, 16)[::-1]
+    fr[0, :, :, 2] = np.arange(256, dtype=np.uint8).reshape(16, 16).T
+    table["norm"] = (fr, 30.0)
+    dsn = ref_rgb.DiDeMoDataset([dict(video="norm", num_segments=1)], dataset_dir="unused")
+    out["norm_frames"] = dsn[0]["frames"].numpy()
+    np.savez_compressed(OUT / "g11_frame_front_end.npz", **out)
+    print("G11", {i: len(out[f"idx_{i}"]) for i in range(len(G11_CASES))}, out["norm_frames"].shape)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                       # python tools/gen_golden.py g11_frame_front_end
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
+    g11_frame_front_end()
     g3_moments_iou()
     g5_tokens()
     g4_pooling()
