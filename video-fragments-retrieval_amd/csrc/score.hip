@@ -1178,7 +1178,7 @@ static int launch_mfma(const ScoreArgs &a, hipStream_t st, int *cap_transposed)
     const int NT = a.ds_rows <= 6 ? 6 : 21, M = NT * (NT + 1) / 2;
     const int kpl = (a.k > 0 && a.k + M > 256) ? 8 : 4;
     if (cap_transposed) *cap_transposed = a.k > 0 ? kpl * 64 : 0;
-    const int RR = NT > 6 ? 48 : 32;
+    const int RR = MF_RING_ROWS(NT);
     const size_t lds = ((size_t)RR * 64 + (size_t)a.num_rank * NT * 64) * sizeof(float);
     ProfScope prof(a.prof_site ? a.prof_site : a.k == 0 ? SITE_SCORE_RANK : SITE_SCORE_FUSED, st);
     dim3 grid((unsigned)tasks);

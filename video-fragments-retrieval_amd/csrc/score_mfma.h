@@ -12,14 +12,14 @@
 //                 (score < x <=> S <= LO, score <= x <=> S <= HI) are widened by Delta_L >= |S~ - S|: a moment is counted when
 //                 S~ <= LO - Delta_L, not counted when S~ > HI + Delta_L, and a (query, video) pair that holds a moment in
 //                 between -- or a clip closer than the distance floor the margin was derived for -- contributes nothing
-//                 here and is queued; score_pairs_exact_kernel re-scores the queued pairs with the canonical chain
-//                 (one pair per lane) and counts them exactly (ties by moment id).
+//                 here and is marked in a (video, query group) bitmap; score_pairs_video_kernel re-scores the marked pairs
+//                 video by video with the canonical chain (lane = query) and counts them exactly (ties by moment id).
 //   top-k         the selection machinery of score.hip runs unchanged on APPROXIMATE keys for k' = k + MF_EXTRA; the
 //                 finisher re-scores those k' candidates exactly and emits the k best.  The exact top-k is contained in
 //                 {s~ <= s~_(k) + 2 delta}, which is inside the k' list whenever s~_(k') > s~_(k) + 2 delta (or fewer than
 //                 k' candidates exist); the finisher checks that per query.
 //   fallback      a query group for which a check fails (more than MF_EXTRA candidates inside the margin -- duplicated
-//                 videos --, pair queue overflow, margins wider than the tables hold) is flagged on the device and answered
+//                 videos --, a key distance too small for any margin) is flagged on the device and answered
 //                 by the exact kernels of score.hip, launched with a group mask; everything else returns at once there.
 //
 // Error margin.  With R = max_c |v_c|, G = (R + |q|)^2 (+ the eps terms):
@@ -45,7 +45,9 @@
 
 constexpr int MF_EXTRA = 28;                 // k' = k + MF_EXTRA candidates by approximate key
 constexpr float MF_U = 5.9604645e-8f;        // 2^-24
+constexpr unsigned MF_WIDTH_MAX = 1u << 28;  // window widths (ulps of the sum) the kernel's shifted 10-bit fields hold
 constexpr int MF_TAB = 4;                    // table words per (query, key, L): LO, HI (exact, exclusive bit bounds), LO wide, width
+#define MF_RING_ROWS(NT) ((NT) > 6 ? 38 : 32)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -54,9 +56,8 @@ struct MfmaArgs {
     const float4 *qmeta;                     // [Nq] {b_q, dfl, E2, R + |q|} (centred norms)
     const unsigned *tab;                     // [Nq][NR][NT][MF_TAB]
     unsigned long long *cnt_ws;              // [NR][Nq] rank counts of this call (committed to count_lt at the end)
-    unsigned long long *queue;               // [tasks][queue_cap] ambiguous pairs: query << 32 | video << 2 | key mask
-    int *queue_cnt;                          // [tasks]
-    int queue_cap;
+    ulonglong2 *amb;                         // [Nv][groups] ambiguous pairs: bit l of .x / .y = query 64 g + l needs key 0 / 1 re-counted
+    unsigned long long *pairs_total;         // [1] marked pairs re-scored exactly (statistics)
     int *fallback;                           // [groups] != 0: answered by the exact kernels
     const unsigned short *vb;                // bf16 mode: V as bf16 [total_clips][128] (zero padded)
     const float *rv;                         // [1] max norm of the CENTRED clip rows (pre-pass)
@@ -208,9 +209,11 @@ __global__ __launch_bounds__(256) void mfma_prep_tab_kernel(int64_t Nq, int NR, 
         if (LOW > LOX) LOW = LOX;
     }
     *reinterpret_cast<uint4 *>(t) = make_uint4(LOX, HIX, LOW, HIW - LOW);
-    // a window wider than the kernel's 10-bit field (a key distance near zero, norms far above the distances): the query's
-    // group goes to the exact kernels right away -- the pre-filter kernel returns at once for a flagged group
-    if (!bf16_mode && HIW - LOW > 1023u) fallback[q >> 6] = 1;
+    // The kernel keeps the widths as 10-bit mantissas under one per-query shift (rounded up: a window is never narrowed), so
+    // a key deep in the tail -- norms far above the key distance, windows of thousands of ulps -- stays on this path: only
+    // its ambiguous pairs cost more.  A key distance so small that no margin exists (delta = inf: the window is the whole
+    // float range) sends the query's group to the exact kernels right away; the pre-filter kernel returns at once for it.
+    if (!bf16_mode && HIW - LOW >= MF_WIDTH_MAX) fallback[q >> 6] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -225,7 +228,10 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
                        const int64_t *__restrict__ mom_off, ScoreArgs a, MfmaArgs m)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int CAP = KPL * 64, RR = NT > 6 ? 48 : 32, NRR = NR > 0 ? NR : 1, NW = (NT + 2) / 3;
+    // ring rows: a tile of 16 clips lands while at most NT - 1 rows of unfinished videos are still live -> NT + 15 rows are
+    // enough; 38 rows (9.5 KB) + the 10.5 KB bound table = 20 KB per wave = eight waves per CU (48 rows left room for seven:
+    // one SIMD of every CU ran a single wave with nothing to cover its operand latency)
+    constexpr int CAP = KPL * 64, RR = MF_RING_ROWS(NT), NRR = NR > 0 ? NR : 1, NW = (NT + 2) / 3;
     constexpr int KS = BF16 ? 4 : 25;                                   // MFMA k-steps per tile
     const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
     const int task = blockIdx.x;
@@ -277,10 +283,24 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
     int cnt = 0, nlt[NRR] = {0};
     unsigned long long *col = TOPK ? a.buf + (size_t)task * 64 * CAP : nullptr;
     float thrf = __builtin_inff();                                       // top-k filter: a moment of L clips may enter when sum <= thrf * L (* 1 + 8u)
-    unsigned wpk[NW];                                                    // 10-bit window width per span length (max over keys), 3 per register
+    unsigned wpk[NW];                                                    // window width per span length (max over keys): 10-bit mantissas, 3 per register ...
+    unsigned wsh = 0u;                                                   // ... under one per-lane shift: width = mantissa << wsh, rounded UP
     bool wide = false;
 #pragma unroll
     for (int w = 0; w < NW; ++w) wpk[w] = 0u;
+    if (NR > 0 && !BF16) {
+        unsigned wmax = 0u;
+#pragma unroll
+        for (int L = 1; L <= NT; ++L)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const unsigned w_ = active ? m.tab[(((active ? qi : 0) * NR + r) * NT + (L - 1)) * MF_TAB + 3] : 0u;
+                wmax = w_ > wmax ? w_ : wmax;
+            }
+        wide = wmax >= MF_WIDTH_MAX;                                      // (its group is flagged by the table pre-pass)
+        const int bits = 32 - __builtin_clz(wmax | 1u);
+        wsh = bits > 10 ? (unsigned)(bits - 10) : 0u;
+    }
 #pragma unroll
     for (int L = 1; L <= NT; ++L) {
         unsigned wd = 0u;
@@ -292,15 +312,13 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
             const unsigned w_ = (active && !BF16) ? e.w : 0u;
             wd = w_ > wd ? w_ : wd;
         }
-        wide = wide || wd > 1023u;
-        wpk[(L - 1) / 3] |= (wd & 1023u) << (10 * ((L - 1) % 3));
+        // mantissa: exact when wsh == 0; otherwise floor + 1 (< 1024 because wmax < 2^(10 + wsh))
+        const unsigned mant = wsh ? (wd >> wsh) + 1u : wd;
+        wpk[(L - 1) / 3] |= (mant & 1023u) << (10 * ((L - 1) % 3));
         asm volatile("" ::: "memory");               // one level's table words in flight at a time (not 42 x 4 registers)
     }
     if (!active) thrf = -1.0f;
 
-    // ---- pair queue of this task (appended to by every launch of the call) ----
-    int qn = NR > 0 && !BF16 ? m.queue_cnt[task] : 0;
-    unsigned long long *queue = m.queue + (size_t)task * m.queue_cap;
 
     // ---- B operand: the clip rows of a tile, k-block by k-block ----
     // f32: 6 blocks of 4 k-steps (one 16-byte load per lane: elements 24 g + 4 b .. + 3 of row j) + the 25th step (element
@@ -323,8 +341,10 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
 
     // per-lane ring addressing (bytes): write = row j of the tile, chunk (4t + g) ^ j; read = chunk (lane >> 2) ^ (row & 15)
     const unsigned rd_lane = (unsigned)(((lane >> 2) << 4) | ((lane & 3) << 2));
-    auto ring_read = [&](int row) -> float {                             // row wave-uniform
-        const unsigned off = (rd_lane ^ ((unsigned)(row & 15) << 4)) + (unsigned)row * 256u;
+    // a clip's ring row is (clip - c_lo) mod RR, its swizzle key (clip - c_lo) & 15: the 16 rows of a tile always carry 16
+    // different keys, wherever the tile wraps
+    auto ring_read = [&](int row, int key) -> float {                    // row, key wave-uniform
+        const unsigned off = (rd_lane ^ ((unsigned)(key & 15) << 4)) + (unsigned)row * 256u;
         return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ring) + off);
     };
 
@@ -390,13 +410,17 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
             }
             bload_bf16((int64_t)c_tile + 16);                            // next tile's operands land under the triangles
         }
+        {
+            int wr = tile_row0 + j;                                      // (tiles start at multiples of 16 clips: key of row j is j)
+            wr = wr >= RR ? wr - RR : wr;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f32x4 o = acc[t] + acv_cur;
-            const unsigned off = (unsigned)(tile_row0 + j) * 256u + ((unsigned)((4 * t + g) ^ j) << 4);
-            *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(ring) + off) = o;
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 o = acc[t] + acv_cur;
+                const unsigned off = (unsigned)wr * 256u + ((unsigned)((4 * t + g) ^ j) << 4);
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(ring) + off) = o;
+            }
         }
-        tile_row0 = tile_row0 + 16 == RR ? 0 : tile_row0 + 16;
+        tile_row0 = tile_row0 + 16 >= RR ? tile_row0 + 16 - RR : tile_row0 + 16;
         const int c_done = c_tile + 16;
 
         // ---- every video whose last clip is in the ring ----
@@ -406,9 +430,9 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
             c_cur = c_nxt;
             ++v;
             if (v < v1) { c_nxt = clip_off[v + 1]; m_cur = mom_off[v]; }
-            int r0 = (c0 - c_lo) % RR;
+            const int r0 = (c0 - c_lo) % RR, k0 = (c0 - c_lo) & 15;
 #ifdef VFR_MF_SKIP_TRI
-            if (ring_read(r0) == 123.456f) nlt[0] += (int)mbase + n;    // timing experiment: no triangle
+            if (ring_read(r0, k0) == 123.456f) nlt[0] += (int)mbase + n;    // timing experiment: no triangle
             continue;
 #endif
             if (TOPK) {
@@ -433,7 +457,7 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
             for (int c = 0; c < NT; ++c) {
                 int row = r0 + c;
                 row = row >= RR ? row - RR : row;
-                const float x2 = ring_read(row) + bq;
+                const float x2 = ring_read(row, k0 + c) + bq;
                 const float dd = __builtin_amdgcn_sqrtf(x2 > 0.0f ? x2 : 0.0f);
                 d[c] = c < n ? dd : __builtin_inff();
                 dmin = d[c] < dmin ? d[c] : dmin;
@@ -447,7 +471,7 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
             for (int L = 1; L <= NT; ++L) {
                 static_assert(NT <= 32, "one 32-bit sign collector per level");
                 unsigned lx[NRR], umin[NRR], below[NRR];
-                const unsigned wd = (wpk[(L - 1) / 3] >> (10 * ((L - 1) % 3))) & 1023u;
+                const unsigned wd = ((wpk[(L - 1) / 3] >> (10 * ((L - 1) % 3))) & 1023u) << wsh;
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     below[r] = 0u;
@@ -490,14 +514,9 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
                     rmask |= (am ? 1u : 0u) << r;
                 }
                 if (!BF16) {
-                    const bool push = active && rmask != 0u;
-                    const unsigned long long mm = __ballot(push);
-                    if (mm) {
-                        const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
-                        if (push && pos < m.queue_cap)
-                            queue[pos] = ((unsigned long long)qi << 32) | ((unsigned long long)(unsigned)(v - 1) << 2) | rmask;
-                        qn += __builtin_popcountll(mm);
-                    }
+                    // every (video, group) slot has exactly one writer (this wave) per call: no atomics, no capacity
+                    const unsigned long long m0 = __ballot(active && (rmask & 1u)), m1 = __ballot(active && (rmask & 2u));
+                    if (lane == 0) m.amb[(size_t)(v - 1) * a.num_groups + group] = ulonglong2{m0, m1};
                 }
             }
             if (TOPK && lvl != 0) {
@@ -505,7 +524,7 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
                 auto dist_at = [&](int c) -> float {                     // per-lane clip index
                     int row = r0 + c;
                     row = row >= RR ? row - RR : row;
-                    const unsigned off = (rd_lane ^ ((unsigned)(row & 15) << 4)) + (unsigned)row * 256u;
+                    const unsigned off = (rd_lane ^ ((unsigned)((k0 + c) & 15) << 4)) + (unsigned)row * 256u;
                     const float x2 = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(ring) + off) + bq;
                     return __builtin_amdgcn_sqrtf(x2 > 0.0f ? x2 : 0.0f);
                 };
@@ -549,10 +568,6 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
         if (active)
             for (int r = 0; r < NR; ++r)
                 if (nlt[r]) atomicAdd(m.cnt_ws + r * a.Nq + qi, (unsigned long long)nlt[r]);
-        if (!BF16 && lane == 0) {
-            m.queue_cnt[task] = qn;
-            if (qn > m.queue_cap) m.fallback[group] = 1;
-        }
     }
     if (TOPK) {
         if (!a.keep_all) {
@@ -565,180 +580,173 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// exact re-scoring of the queued (query, video) pairs.  One wave per task queue, 64 pairs at a time:
-//   phase 1  the canonical distance chains, lane = (pair, clip): the queue is in video order, so the pairs of one video are
-//            consecutive; the video's clip rows are staged into LDS with coalesced 16-byte loads (the next video's rows in
-//            flight meanwhile) and every lane runs one k-ascending chain -- v from LDS, q from the pair's query row (L1);
-//   phase 2  lane = pair: its clip distances come back through LDS, then the moment triangle against the EXACT bounds of
-//            the table (ties broken by moment id on the exact score).
+// exact re-scoring of the marked (query, video) pairs, video by video.  One wave per video:
+//   * the video's clip rows are staged once into LDS (coalesced 16-byte loads);
+//   * the (group, key) bitmaps of the video are expanded, 64 query groups at a time, into a compact list of its marked
+//     queries (lane = group: popcount, wave scan, every lane writes its own set bits);
+//   * 64 pairs at a time, lane = query: the query row is gathered into registers, the canonical k-ascending chains of the
+//     video's clips run with the clip row BROADCAST from LDS (what score_fast_kernel does for all pairs -- the same
+//     instruction mix, full lanes), then the moment triangle against the EXACT bit bounds of the table (LOX / HIX: no
+//     division); a sum that lands exactly on a key (LOX <= bits < HIX) sends the lane through the tie walk (ids compared).
+// (Round 2 queued pairs per wave-task of the pre-filter kernel, in video order, and ran the chains with lane = (pair, clip)
+// from per-lane LDS reads: ~4.5 pairs shared a video, 75 % of the lanes worked and the kernel waited on LDS -- 2.2 ms for the
+// 7 % of pairs of the bench corpus.)
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int PV_LIST = 4096;                // list entries per 64-group chunk (every query of the chunk marked)
 template <int NT, int NR>
-__global__ __launch_bounds__(64) void score_pairs_exact_kernel(const float *__restrict__ Qp, const float *__restrict__ Vp,
+__global__ __launch_bounds__(64) void score_pairs_video_kernel(const float *__restrict__ Qp, const float *__restrict__ Vp,
                                                                const int32_t *__restrict__ clip_off,
                                                                const int64_t *__restrict__ mom_off,
                                                                const float *__restrict__ rank_dist,
                                                                const int64_t *__restrict__ rank_idx, ScoreArgs a, MfmaArgs m)
 {
-    constexpr int ROW4 = FAST_D / 4, NLD = (NT * ROW4 + 63) / 64, QR = 16, NLQ = (QR * ROW4 + 63) / 64;
-    __shared__ __attribute__((aligned(16))) float vst[NT * FAST_D];     // clip rows of the current video
-    __shared__ __attribute__((aligned(16))) float qst[QR * FAST_D];     // query rows of the current run of pairs (<= QR)
-    __shared__ float dx[64 * NT];                                        // exact distances [pair][clip]
-    const int lane = threadIdx.x, task = blockIdx.x;
-    const int group = task % a.num_groups;
-    const int total = m.queue_cnt[task];
-    if (total <= 0 || total > m.queue_cap || m.fallback[group]) return;
-    const unsigned long long *queue = m.queue + (size_t)task * m.queue_cap;
-    const float4 *V4 = reinterpret_cast<const float4 *>(Vp);
-    const int64_t v4_end = (int64_t)a.total_clips * ROW4;
-    float4 pre[NLD], preq[NLQ];
-    auto gload = [&](int c0) {                                           // NT rows from clip c0 (clamped at the end of V)
+    static_assert(NR == 2, "two rank keys per query (the bitmap holds one mask per key)");
+    constexpr int ROW4 = FAST_D / 4, NLD = (NT * ROW4 + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float vst[NT * FAST_D];     // clip rows of this video
+    __shared__ unsigned short list[PV_LIST];                             // (group in chunk) << 8 | lane bit << 2 | key mask
+    __shared__ float dx[64 * (NT + 1)];                                  // tie walk only: exact distances [pair][clip]
+    const int lane = threadIdx.x, v = blockIdx.x;
+    const int groups = a.num_groups;
+    const int c0 = clip_off[v], n = clip_off[v + 1] - c0;
+    const int64_t mbase = mom_off[v];
+    {
+        const float4 *V4 = reinterpret_cast<const float4 *>(Vp);
+        const int64_t v4_end = (int64_t)a.total_clips * ROW4;
 #pragma unroll
         for (int t = 0; t < NLD; ++t) {
             const int idx = lane + 64 * t;
             const int64_t g4 = (int64_t)c0 * ROW4 + idx;
-            pre[t] = (idx < NT * ROW4 && g4 < v4_end) ? V4[g4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NT * ROW4) reinterpret_cast<float4 *>(vst)[idx] = g4 < v4_end ? V4[g4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    };
-    auto swrite = [&]() {
-#pragma unroll
-        for (int t = 0; t < NLD; ++t) {
-            const int idx = lane + 64 * t;
-            if (idx < NT * ROW4) reinterpret_cast<float4 *>(vst)[idx] = pre[t];
-        }
-    };
+    }
     const float2v e2 = {a.eps, a.eps};
-    for (int base = 0; base < total; base += 64) {
-        const int nb = total - base < 64 ? total - base : 64;
-        const bool have = lane < nb;
-        const unsigned long long ent = queue[base + (have ? lane : nb - 1)];
-        const int64_t qi = (int64_t)(ent >> 32);
-        const int v = (int)((ent >> 2) & 0x3FFFFFFFu);
-        const unsigned rmask = have ? (unsigned)(ent & 3u) : 0u;
-        const int qlo = (int)qi;                                         // (query index < 2^31)
-        auto gload_q = [&](int first, int rows) {                        // query rows of pairs [first, first + rows) -> registers
+    unsigned long long npairs = 0;
+    for (int gb = 0; gb < groups; gb += 64) {
+        // ---- expand the bitmaps of groups gb .. gb + 63 ----
+        const int g = gb + lane;
+        ulonglong2 mm = ulonglong2{0ull, 0ull};
+        if (g < groups && !m.fallback[g]) mm = m.amb[(size_t)v * groups + g];
+        const unsigned long long any = mm.x | mm.y;
+        const int c = __builtin_popcountll(any);
+        int incl = c;
 #pragma unroll
-            for (int t = 0; t < NLQ; ++t) {
-                const int idx = lane + 64 * t, rr = idx / ROW4, j4 = idx - rr * ROW4;
-                const int src = __shfl(qlo, first + (rr < rows ? rr : 0), 64);
-                preq[t] = rr < rows ? reinterpret_cast<const float4 *>(Qp + (int64_t)src * FAST_D)[j4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); incl += lane >= o ? t : 0; }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total == 0) continue;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                              // the previous chunk's list reads are done
+        {
+            int pos = incl - c;
+            unsigned long long rest = any;
+            while (rest) {
+                const int b = __builtin_ctzll(rest);
+                rest &= rest - 1ull;
+                list[pos++] = (unsigned short)((lane << 8) | (b << 2) | (unsigned)((mm.x >> b) & 1ull) | ((unsigned)((mm.y >> b) & 1ull) << 1));
             }
-        };
-        auto swrite_q = [&]() {
-#pragma unroll
-            for (int t = 0; t < NLQ; ++t) {
-                const int idx = lane + 64 * t;
-                if (idx < QR * ROW4) reinterpret_cast<float4 *>(qst)[idx] = preq[t];
-            }
-        };
-        auto run_at = [&](int at) -> int {                               // consecutive pairs of the video of pair `at`, <= QR
-            const int vv = __builtin_amdgcn_readlane(v, at);
-            const unsigned long long same = __ballot(v == vv) >> at;
-            int run = same == ~0ull ? 64 - at : __builtin_ctzll(~same);
-            run = run < nb - at ? run : nb - at;
-            return run < QR ? run : QR;
-        };
-        // ---- phase 1 ----
-        int idx = 0, run = run_at(0);
-        gload(clip_off[__builtin_amdgcn_readlane(v, 0)]);
-        gload_q(0, run);
-        while (idx < nb) {
-            const int vv = __builtin_amdgcn_readlane(v, idx);
-            const int c0 = clip_off[vv], n = clip_off[vv + 1] - c0;
-            (void)c0;
-            __builtin_amdgcn_s_waitcnt(0xC07F);                         // earlier LDS reads of vst / qst are done (one wave: in order)
-            swrite();
-            swrite_q();
-            const int nxt = idx + run;
-            int run_n = 0;
-            if (nxt < nb) {                                              // next run's rows in flight under this run's chains
-                run_n = run_at(nxt);
-                gload(clip_off[__builtin_amdgcn_readlane(v, nxt)]);
-                gload_q(nxt, run_n);
-            }
-            const int chains = run * n;
-            for (int cb = 0; cb < chains; cb += 64) {
-                const int id = cb + lane;
-                const bool on = id < chains;
-                const int pl = on ? id / n : 0, c = on ? id - pl * n : 0;
-                const float4 *q4 = reinterpret_cast<const float4 *>(qst + pl * FAST_D);
-                const float4 *v4 = reinterpret_cast<const float4 *>(vst + c * FAST_D);
-                float acc = 0.0f;
-#ifdef VFR_PAIRS_SKIP_CHAIN
-                acc = v4[lane & 15].x + q4[lane & 7].y;                  // timing experiment: no chain
-#else
-#pragma unroll 5
-                for (int j4 = 0; j4 < ROW4; ++j4) {
-                    const float4 x = v4[j4], y = q4[j4];
-                    const float2v d01 = (float2v{x.x, x.y} - float2v{y.x, y.y}) + e2;
-                    const float2v d23 = (float2v{x.z, x.w} - float2v{y.z, y.w}) + e2;
-                    acc = __builtin_fmaf(d01.x, d01.x, acc);
-                    acc = __builtin_fmaf(d01.y, d01.y, acc);
-                    acc = __builtin_fmaf(d23.x, d23.x, acc);
-                    acc = __builtin_fmaf(d23.y, d23.y, acc);
-                }
-#endif
-                if (on) dx[(idx + pl) * NT + c] = __builtin_sqrtf(acc);
-            }
-            idx = nxt;
-            run = run_n;
         }
+        npairs += (unsigned long long)total;
         __builtin_amdgcn_s_waitcnt(0xC07F);
-#ifdef VFR_PAIRS_SKIP_P2
-        if (dx[lane] == 123.456f) atomicAdd(m.cnt_ws + qi, 1ull);      // timing experiment: no triangle
-        continue;
-#endif
-        // ---- phase 2 ----
-        const int c0 = clip_off[v], n = clip_off[v + 1] - c0;
-        const int64_t mbase = mom_off[v];
-        float d[NT];
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < total; base += 64) {
+            const bool have = base + lane < total;
+            const unsigned ent = list[have ? base + lane : base];
+            const unsigned rmask = have ? (ent & 3u) : 0u;
+            int64_t qi = (int64_t)(gb + (int)(ent >> 8)) * 64 + ((ent >> 2) & 63u);
+            qi = qi < a.Nq ? qi : a.Nq - 1;
+            // ---- the query row, then the canonical chains (clip rows broadcast from LDS) ----
+            float2v qp[FAST_D / 2];
+            {
+                const float4 *q4 = reinterpret_cast<const float4 *>(Qp + qi * FAST_D);
 #pragma unroll
-        for (int c = 0; c < NT; ++c) d[c] = (have && c < n) ? dx[lane * NT + c] : __builtin_inff();
-        // every lane has its own query's keys: the exact score (IEEE division, as the reference path computes it) against the
-        // key distance -- no per-lane table rows to gather
-        int cntr[NR] = {0};
-        float sums[NT], xk[NR];
+                for (int j4 = 0; j4 < ROW4; ++j4) {
+                    const float4 y = q4[j4];
+                    qp[2 * j4] = float2v{y.x, y.y}; qp[2 * j4 + 1] = float2v{y.z, y.w};
+                }
+            }
+            float d[NT];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) xk[r] = rank_dist[r * a.Nq + qi];
-        bool tie = false;
+            for (int cc = 0; cc < NT; ++cc) {
+                d[cc] = __builtin_inff();
+                if (cc < n) {                                            // wave-uniform
+                    const float4 *v4 = reinterpret_cast<const float4 *>(vst + cc * FAST_D);
+                    float acc = 0.0f;
 #pragma unroll
-        for (int L = 1; L <= NT; ++L) {
+                    for (int j4 = 0; j4 < ROW4; ++j4) {
+                        const float4 x = v4[j4];
+                        const float2v d01 = (float2v{x.x, x.y} - qp[2 * j4]) + e2;
+                        const float2v d23 = (float2v{x.z, x.w} - qp[2 * j4 + 1]) + e2;
+                        acc = __builtin_fmaf(d01.x, d01.x, acc);
+                        acc = __builtin_fmaf(d01.y, d01.y, acc);
+                        acc = __builtin_fmaf(d23.x, d23.x, acc);
+                        acc = __builtin_fmaf(d23.y, d23.y, acc);
+                    }
+                    d[cc] = __builtin_sqrtf(acc);
+                }
+            }
+            // ---- exact triangle: bits(sum) against the table's exclusive bounds (score < x <=> bits < LOX) ----
+            const unsigned *tq = m.tab + (size_t)qi * NR * NT * MF_TAB;
+            int cntr[NR] = {0, 0};
+            bool tie = false;
+            float sums[NT];
 #pragma unroll
-            for (int s = 0; s + L <= NT; ++s) {
-                const float de = d[s + L - 1];
-                const float sum = L == 1 ? de : sums[s] + de;
-                sums[s] = sum;
-                const float sc = sum / (float)L;
+            for (int L = 1; L <= NT; ++L) {
+                unsigned lox[NR], dhl[NR], below[NR], umin[NR];
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    cntr[r] += sc < xk[r] ? 1 : 0;
-                    tie = tie || sc == xk[r];
+                    const uint2 e = *reinterpret_cast<const uint2 *>(tq + (r * NT + (L - 1)) * MF_TAB);
+                    lox[r] = e.x; dhl[r] = e.y - e.x; below[r] = 0u; umin[r] = 0xFFFFFFFFu;
                 }
-            }
-        }
-        if (__ballot(tie && rmask != 0u)) {
-            // score == a rank key somewhere: walk this lane's video once more and break the ties by moment id
-            if (tie) {
-#pragma nounroll
-                for (int s = 0; s < n; ++s) {
-                    float sum = 0.0f;
-#pragma nounroll
-                    for (int e = s; e < n; ++e) {
-                        const float de = dx[lane * NT + e];
-                        sum = e == s ? de : sum + de;
-                        const float sc = sum / (float)(e - s + 1);
-                        const unsigned id = (unsigned)(a.id_base + mbase + moment_index(n, s, e));
 #pragma unroll
-                        for (int r = 0; r < NR; ++r)
-                            if (sc == xk[r] && id < (unsigned)rank_idx[r * a.Nq + qi]) cntr[r] += 1;
+                for (int s2 = 0; s2 + L <= NT; ++s2) {
+                    const float de = d[s2 + L - 1];
+                    const float sum = L == 1 ? de : sums[s2] + de;
+                    sums[s2] = sum;
+                    const unsigned sb = __float_as_uint(sum);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const unsigned u = sb - lox[r];
+                        below[r] = __builtin_amdgcn_alignbit(below[r], u, 31);
+                        umin[r] = u < umin[r] ? u : umin[r];
                     }
                 }
-            }
-        }
 #pragma unroll
-        for (int r = 0; r < NR; ++r)
-            if (((rmask >> r) & 1u) && cntr[r]) atomicAdd(m.cnt_ws + r * a.Nq + qi, (unsigned long long)cntr[r]);
-        __builtin_amdgcn_s_waitcnt(0xC07F);                             // dx is rewritten by the next batch
+                for (int r = 0; r < NR; ++r) {
+                    cntr[r] += __builtin_popcount(below[r]);
+                    tie = tie || umin[r] < dhl[r];
+                }
+            }
+            if (__ballot(tie && rmask != 0u)) {
+                // bits(sum) inside [LOX, HIX) somewhere: score == a key distance; this lane's video once more with the quotients,
+                // ties broken by moment id (the distances go through LDS: the walk indexes them dynamically)
+#pragma unroll
+                for (int cc = 0; cc < NT; ++cc) dx[lane * (NT + 1) + cc] = d[cc];
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                if (tie) {
+                    float xk[NR];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) xk[r] = rank_dist[r * a.Nq + qi];
+#pragma nounroll
+                    for (int s2 = 0; s2 < n; ++s2) {
+                        float sum = 0.0f;
+#pragma nounroll
+                        for (int e = s2; e < n; ++e) {
+                            const float de = dx[lane * (NT + 1) + e];
+                            sum = e == s2 ? de : sum + de;
+                            const float sc = sum / (float)(e - s2 + 1);
+                            const unsigned id = (unsigned)(a.id_base + mbase + moment_index(n, s2, e));
+#pragma unroll
+                            for (int r = 0; r < NR; ++r)
+                                if (sc == xk[r] && id < (unsigned)rank_idx[r * a.Nq + qi]) cntr[r] += 1;
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (((rmask >> r) & 1u) && cntr[r]) atomicAdd(m.cnt_ws + r * a.Nq + qi, (unsigned long long)cntr[r]);
+        }
     }
+    if (lane == 0 && npairs) atomicAdd(m.pairs_total, npairs);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
