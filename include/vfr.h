@@ -134,10 +134,15 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
  *                       max_clips <= 21, num_rank in {0, 2}, k <= 253; VFR_EUNSUPPORTED otherwise.
  * Arguments as vfr_score_topk_f32.
  * dtype | VFR_MFMA_BANK_READY: the caller states that `workspace` was last used by a pre-filter call (one for which
- * vfr_score_topk_mfma_prefilter returned 1) on exactly this bank -- same V contents, offsets and base dtype, any Nq / k --
- * and has not been written since: the bank-side products (mean, centred rows, norms; they sit at the front of the
- * workspace at offsets that depend on total_clips alone) are reused instead of recomputed.  For serving many query batches
- * against one resident bank (0.1-0.15 ms per call at 210 000 clips).  Not checked.
+ * vfr_score_topk_mfma_prefilter returned 1) on this bank and has not been written since: the bank-side products (mean,
+ * centred rows, norms; they sit at the front of the workspace at offsets that depend on total_clips alone) are reused
+ * instead of recomputed.  For serving many query batches against one resident bank (~0.1 ms per call at 210 000 clips).
+ * CHECKED ON THE DEVICE: every call hashes all of V and the clip offsets (64-bit position-weighted sum, ~20 us at 84 MB)
+ * and compares {hash, total_clips, Nv, D, eps, bf16 copy present} with the signature stored next to the products; on any
+ * difference the products are recomputed inside the same call (the pre-pass kernels are always enqueued and return at once
+ * when the signature matches -- no host decision, no synchronisation).  A bank rewritten through a raw pointer therefore
+ * costs a recomputation, never a wrong result.  NOT checked: that the product region of `workspace` itself is intact --
+ * that part stays the caller's statement (do not set the flag for a workspace other code has used in between).
  * vfr_score_topk_mfma_prefilter: 1 if a call with these shapes runs the pre-filter (and therefore leaves the bank-side
  * products in its workspace), 0 if it is handed to the exact kernels.                            */
 #define VFR_MFMA_F32 0
@@ -152,7 +157,7 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
                         int dtype, void *workspace, size_t workspace_bytes, vfr_stream_t stream);
 /* measurement hook (SYNCHRONISES the stream): what the last f32 call on `workspace` (same Nq, Nv, total_clips, k) left to
  * the exact kernels.  stats_host[4] = {query groups of 64, groups handed to the exact fallback, (query, video) pairs
- * re-scored exactly, capacity of the pair queues}.                                             */
+ * re-scored exactly, pairs the (video, group) bitmap can mark = Nq * Nv}.                                             */
 int vfr_score_topk_mfma_stats(const void *workspace, int64_t Nq, int Nv, int total_clips, int k, int64_t *stats_host,
                               vfr_stream_t stream);
 /* merge G per-shard top-k lists (after the RCCL all-gather): part_dist/part_idx

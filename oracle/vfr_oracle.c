@@ -602,3 +602,86 @@ VFO_EXPORT void vfo_adaptive_avgpool7(const float *x, int B, int C, int H, int W
                 y[p * 49 + oy * 7 + ox] = acc / (float)((y1 - y0) * (x1 - x0));
             }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* f4  ResNet-152 up to the global average pool (get_rgb_features.py:127-131: torchvision      */
+/* resnet152, children()[:-1] = conv1, bn1, relu, maxpool, layer1..4, avgpool -> [T, 2048, 1, 1];*/
+/* torchvision is absent here and its version is unpinned: arithmetic restated from the public  */
+/* architecture -- Bottleneck blocks (1x1, 3x3 carrying the stride, 1x1 x4; 1x1 downsample on   */
+/* the first block of a layer), counts 3/8/36/3 -- and pinned against a torch.nn composition    */
+/* (tests/golden G12).                                                                          */
+/*   eval-mode BatchNorm folded into the convolution: invstd = 1 / sqrt(var + eps),             */
+/*   alpha = gamma * invstd, w' = w * alpha (per output channel), beta = fma(-mean, alpha, b);  */
+/*   conv: one chain per output over k = (ky*KW + kx)*Cin + ci ascending (tap-major,            */
+/*   channel-minor -- the order an NHWC implicit GEMM consumes), padding contributes nothing;   */
+/*   then v = acc + beta, v = v + identity (when the block adds its input), ReLU.               */
+/* ------------------------------------------------------------------------------------------ */
+VFO_EXPORT void vfo_bn_fold(const float *w, const float *bn /* [4][Cout]: gamma, b, mean, var */, int Cout, int K, float eps,
+                            float *wf, float *beta)
+{
+    for (int co = 0; co < Cout; ++co) {
+        const float invstd = 1.0f / sqrtf(bn[3 * Cout + co] + eps);
+        const float alpha = bn[co] * invstd;
+        for (int k = 0; k < K; ++k) wf[(size_t)co * K + k] = w[(size_t)co * K + k] * alpha;
+        beta[co] = fmaf(-bn[2 * Cout + co], alpha, bn[Cout + co]);
+    }
+}
+VFO_EXPORT void vfo_conv2d(const float *x, int B, int Cin, int H, int W, const float *wf /* [Cout,Cin,KH,KW] folded */,
+                           const float *beta, int Cout, int KH, int KW, int stride, int pad, const float *res, int relu, float *y)
+{
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+#pragma omp parallel for collapse(2) schedule(static) num_threads(g_threads)
+    for (int n = 0; n < B; ++n)
+        for (int co = 0; co < Cout; ++co) {
+            float *acc = (float *)calloc((size_t)Ho * Wo, sizeof(float));
+            for (int ky = 0; ky < KH; ++ky)
+                for (int kx = 0; kx < KW; ++kx)
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        const float wv = wf[(((size_t)co * Cin + ci) * KH + ky) * KW + kx];
+                        const float *xp = x + ((size_t)n * Cin + ci) * H * W;
+                        for (int oy = 0; oy < Ho; ++oy) {
+                            const int iy = oy * stride + ky - pad;
+                            if (iy < 0 || iy >= H) continue;
+                            for (int ox = 0; ox < Wo; ++ox) {
+                                const int ix = ox * stride + kx - pad;
+                                if (ix < 0 || ix >= W) continue;
+                                acc[oy * Wo + ox] = fmaf(xp[iy * W + ix], wv, acc[oy * Wo + ox]);
+                            }
+                        }
+                    }
+            float *yp = y + ((size_t)n * Cout + co) * Ho * Wo;
+            const float *rp = res ? res + ((size_t)n * Cout + co) * Ho * Wo : NULL;
+            for (int i = 0; i < Ho * Wo; ++i) {
+                float v = acc[i] + beta[co];
+                if (rp) v = v + rp[i];
+                yp[i] = (relu && !(v > 0.0f)) ? 0.0f : v;
+            }
+            free(acc);
+        }
+}
+/* MaxPool2d(kernel 3, stride 2, padding 1): the padding never wins (torch pads with -inf) */
+VFO_EXPORT void vfo_maxpool3s2(const float *x, int B, int C, int H, int W, float *y)
+{
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    for (size_t p = 0; p < (size_t)B * C; ++p)
+        for (int oy = 0; oy < Ho; ++oy)
+            for (int ox = 0; ox < Wo; ++ox) {
+                float m = -INFINITY;
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
+                        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                        m = fmaxf(m, x[p * H * W + (size_t)iy * W + ix]);
+                    }
+                y[p * Ho * Wo + (size_t)oy * Wo + ox] = m;
+            }
+}
+/* AdaptiveAvgPool2d((1,1)): row-major sum of the plane / (H*W) */
+VFO_EXPORT void vfo_global_avgpool(const float *x, int B, int C, int H, int W, float *y)
+{
+    for (size_t p = 0; p < (size_t)B * C; ++p) {
+        float acc = 0.0f;
+        for (int i = 0; i < H * W; ++i) acc = acc + x[p * H * W + i];
+        y[p] = acc / (float)(H * W);
+    }
+}

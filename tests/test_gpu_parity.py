@@ -551,6 +551,18 @@ def test_prefilter_bank_products_reused_only_while_valid(vfr, mode):
         check(bank, 64, False)                      # ... and back: the workspace holds bank2's products
         vfr.score_topk(dev(rs.randn(8, 100).astype(np.float32)), bank, 10, workspace=ws, mode="exact")
         check(bank, 64, False)                      # the exact kernels carved the workspace their own way
+        # writes torch does not version (the host-side token still matches, so the call CLAIMS VFR_MFMA_BANK_READY): the
+        # library hashes the bank on the device, finds the signature stale and recomputes -- results stay right
+        check(bank, 64, True)
+        bank.emb.data.mul_(0.5)                     # whole tensor through .data: _version does not move
+        check(bank, 64, True)
+        alias = torch.from_dlpack(torch.utils.dlpack.to_dlpack(bank.emb))
+        alias[int(off[150]) + 1, 17] += 0.25        # ONE element of one clip row, through a DLPack alias
+        check(bank, 64, True)
+        bank.emb.data[-1, 99] = -bank.emb.data[-1, 99]   # the last word of the bank
+        check(bank, 64, True)
+        bank.invalidate()                           # the explicit way: the claim is not even made
+        check(bank, 64, False)
     finally:
         vfr.set_option("score_mfma_min", 128)
 

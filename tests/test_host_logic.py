@@ -253,6 +253,31 @@ def test_engine_exchange_helpers_on_cpu():
         engine._all_gather_rows(Fails(), torch.empty((3, 2, 3), dtype=torch.int64), mine)
     assert ListOnly.calls == 1                                   # no silent switch to another collective
 
+    class OldGloo(ListOnly):
+        """a torch.distributed whose gloo group refuses the tensor form (older builds): every rank must settle on the list
+        form ONCE, through a probe whose outcome is reduced over the ranks -- not per call, not per rank"""
+        probes = reduces = 0
+
+        class ReduceOp:
+            MIN = "min"
+
+        def get_backend(self): return "gloo"
+        def get_world_size(self): return 3
+
+        def all_gather_into_tensor(self, out, t):
+            OldGloo.probes += 1
+            raise RuntimeError("ProcessGroupGloo does not support _allgather_base")
+
+        def all_reduce(self, t, op=None):
+            OldGloo.reduces += 1                                 # (single process: the MIN over the ranks is this rank's value)
+
+    old = OldGloo()
+    for _ in range(2):
+        out = torch.empty((3, 2, 3), dtype=torch.int64)
+        engine._all_gather_rows(old, out, mine)
+        assert all(torch.equal(out[g], mine + g) for g in range(3))
+    assert (OldGloo.probes, OldGloo.reduces) == (1, 1)           # probed once, then remembered
+
 
 @pytest.mark.parametrize("clips", [6, "didemo", 21])
 def test_gt_label_table_vectorised_equals_get_iou_loop(clips):
@@ -275,6 +300,15 @@ def test_gt_label_table_vectorised_equals_get_iou_loop(clips):
     t, na = engine.pack_times(times)
     assert t.shape == (400, 6, 2) and na.tolist() == [6 if i % 3 == 0 else 4 for i in range(400)]
     assert engine.gt_label_table([], np.zeros(0, int), [0.5]).shape == (1, 0, 0)
+    # spans far outside the clip range (a foreign annotation file) take the per-query form instead of a (T - lo)^2 table
+    far = [[[0, 1], [0, 1], [5000, 9000], [2, 4000]] for _ in range(5)] + [[[3, 3], [3, 3], [3, 4], [70, 90]]]
+    cf = np.array([6, 6, 6, 6, 6, 5])
+    lab = engine.gt_label_table(far, cf, [0.5, 0.7])
+    for q in range(6):
+        mom = vutils.generate_moments(int(cf[q]))
+        for r, thr in enumerate([0.5, 0.7]):
+            want = [int((vutils.get_iou(far[q], s, e) > thr).sum() >= 2) for s, e in mom]
+            assert lab[r, q, :len(mom)].astype(int).tolist() == want
 
 
 @pytest.mark.parametrize("tag,clips", [("n6", 6), ("ragged", "didemo")])

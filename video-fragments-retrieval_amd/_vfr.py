@@ -8,6 +8,7 @@ shared library is missing or a tensor is not on the GPU these functions raise.
 from __future__ import annotations
 
 import ctypes
+import itertools
 import os
 import subprocess
 from pathlib import Path
@@ -255,16 +256,22 @@ class VideoBank:
         self.total_clips = int(self.emb.shape[0])
         self.id_base = int(id_base)
         self.dim = int(self.emb.shape[1])
-        VideoBank._serial += 1
-        self.serial = VideoBank._serial          # identity of this bank's contents for the workspace-side cache (score_topk)
+        self.serial = next(VideoBank._counter)   # identity of this bank object for the workspace-side cache (score_topk); atomic under the GIL
 
-    _serial = 0
+    _counter = itertools.count(1)
 
-    def prep_token(self, dtype: int):
-        """What must be unchanged for the bank-side products of the MFMA pre-filter to be reusable: this object, no in-place
-        torch edit of its tensors since, the base dtype."""
+    def invalidate(self) -> None:
+        """Forget every workspace-side product computed for this bank (call after writing ``emb`` / ``clip_off`` through
+        anything torch does not version: ``.data``, DLPack / numpy views, a raw-pointer kernel).  Not needed for
+        correctness -- the library hashes the bank on the device before it reuses anything (include/vfr.h,
+        VFR_MFMA_BANK_READY) -- but it saves that call the hash + compare."""
+        self.serial = next(VideoBank._counter)
+
+    def prep_token(self, dtype: int, eps: float = 1e-6):
+        """When the host may CLAIM the bank-side products of the MFMA pre-filter as reusable: this object, no torch-versioned
+        in-place edit of its tensors since, the base dtype, the same eps.  The claim is verified on the device."""
         return (self.serial, self.emb.data_ptr(), self.emb._version, self.clip_off.data_ptr(), self.clip_off._version,
-                self.num_videos, self.total_clips, int(dtype))
+                self.num_videos, self.total_clips, int(dtype), float(eps))
 
 
 def slice_bank(bank: VideoBank, counts, v0: int, v1: int) -> VideoBank:
@@ -349,7 +356,7 @@ def score_topk(Q: torch.Tensor, bank: VideoBank, k: int, rank_dist=None, rank_id
     else:
         # the bank-side products of the pre-filter stay in the workspace: a later call on the SAME bank object (and untouched
         # tensors) with this workspace reuses them (VFR_MFMA_BANK_READY); anything else recomputes
-        token = bank.prep_token(dtype)
+        token = bank.prep_token(dtype, eps)
         ready = getattr(workspace, "_vfr_bank", None) == token
         pre = lib().vfr_score_topk_mfma_prefilter(Nq, bank.num_videos, bank.total_clips, bank.max_clips, bank.dim, R, k, dtype)
         workspace._vfr_bank = None
@@ -365,7 +372,7 @@ def score_mfma_stats(workspace: torch.Tensor, Nq: int, bank: VideoBank, k: int) 
     out = (ctypes.c_int64 * 4)()
     _check(lib().vfr_score_topk_mfma_stats(workspace.data_ptr(), Nq, bank.num_videos, bank.total_clips, k, out, _stream()),
            "vfr_score_topk_mfma_stats")
-    return {"groups": out[0], "fallback_groups": out[1], "exact_pairs": out[2], "queue_capacity": out[3],
+    return {"groups": out[0], "fallback_groups": out[1], "exact_pairs": out[2], "markable_pairs": out[3],
             "exact_pair_fraction": out[2] / float(max(1, Nq * bank.num_videos))}
 
 

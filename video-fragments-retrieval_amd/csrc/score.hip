@@ -17,6 +17,7 @@
 //   * keys are (fp32 bits of score << 32 | moment id): scores are >= 0 so unsigned order == the (score, id) lexicographic
 //     order, one 64-bit compare per test.
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "vfr_common.h"
@@ -1431,8 +1432,8 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
 // ---- MFMA pre-filter path (score_mfma.h) ------------------------------------------------------------------------------
 namespace vfr {
 struct MfmaWs {
-    float *rv; int *fallback; int *queue_cnt; unsigned long long *cnt_ws; size_t zero_bytes; char *zero_base;
-    float *va; float4 *qmeta; unsigned *tab; unsigned short *vb; unsigned long long *queue; int queue_cap; int tasks, groups;
+    float *rv; BankSig *sig; unsigned long long *hash_now; int *stale; int *fallback; unsigned long long *pairs_total; unsigned long long *cnt_ws; size_t zero_bytes; char *zero_base;
+    float *va; float4 *qmeta; unsigned *tab; unsigned *wmax; unsigned short *vb; ulonglong2 *amb; int tasks, groups;
     float *mu, *vc, *qc; double *mean_partial; int mean_blocks, mean_rows;
     void *topk; size_t topk_bytes; size_t total;
 };
@@ -1442,14 +1443,12 @@ static MfmaWs carve_mfma(void *base, int64_t Nq, int Nv, int total_clips, int k)
     int g, c;
     plan_tasks(Nq, Nv, &g, &c);
     w.groups = g; w.tasks = g * c;
-    const int nb = Nv >= 256 ? pre_b_videos(Nv) : 0;
-    const int per = (int)cdiv(Nv - nb > 0 ? Nv - nb : 1, c) + (int)cdiv(nb, c) + 2;
-    w.queue_cap = 16 * per < 128 ? 128 : 16 * per;                       // a quarter of the task's (query, video) pairs
     size_t off = 0;
     auto take = [&](size_t bytes) { char *p = static_cast<char *>(base) + off; off += align_up(bytes, 256); return p; };
     // bank side first, at offsets that depend on the bank alone (total_clips): a caller that scores many query batches against
     // one resident bank keeps these across calls (VFR_MFMA_BANK_READY)
     w.rv = reinterpret_cast<float *>(take(4));
+    w.sig = reinterpret_cast<BankSig *>(take(sizeof(BankSig)));          // what the products below were computed from (guard of BANK_READY)
     w.mean_rows = 512;
     w.mean_blocks = (int)cdiv(total_clips > 0 ? total_clips : 1, w.mean_rows);
     w.mu = reinterpret_cast<float *>(take(128 * 4));
@@ -1460,14 +1459,18 @@ static MfmaWs carve_mfma(void *base, int64_t Nq, int Nv, int total_clips, int k)
     // zeroed at every call
     w.zero_base = static_cast<char *>(base) + off;
     const size_t z0 = off;
+    w.hash_now = reinterpret_cast<unsigned long long *>(take(8));
+    w.stale = reinterpret_cast<int *>(take(4));
     w.fallback = reinterpret_cast<int *>(take((size_t)g * 4));
-    w.queue_cnt = reinterpret_cast<int *>(take((size_t)w.tasks * 4));
+    w.pairs_total = reinterpret_cast<unsigned long long *>(take(8));
     w.cnt_ws = reinterpret_cast<unsigned long long *>(take((size_t)MAX_RANK * Nq * 8));
+    w.wmax = reinterpret_cast<unsigned *>(take((size_t)Nq * 4));
     w.zero_bytes = off - z0;
     w.qc = reinterpret_cast<float *>(take((size_t)Nq * FAST_D * 4));
     w.qmeta = reinterpret_cast<float4 *>(take((size_t)Nq * 16));
     w.tab = reinterpret_cast<unsigned *>(take((size_t)Nq * 2 * 21 * MF_TAB * 4));
-    w.queue = reinterpret_cast<unsigned long long *>(take((size_t)w.tasks * w.queue_cap * 8));
+    // ambiguous-pair bitmap: two 64-bit masks per (video, query group), every slot written by exactly one wave per call
+    w.amb = reinterpret_cast<ulonglong2 *>(take((size_t)(Nv > 0 ? Nv : 1) * g * sizeof(ulonglong2)));
     w.topk_bytes = carve_topk(nullptr, Nq, Nv, k > 0 ? k + MF_EXTRA : 0).total;
     w.topk = take(w.topk_bytes);
     w.total = off;
@@ -1773,26 +1776,35 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
     vfr::TopkWs w = vfr::carve_topk(mw.topk, Nq, Nv, kp);
     if (hipMemsetAsync(mw.zero_base, 0, mw.zero_bytes, st) != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: hipMemsetAsync failed");
     vfr::MfmaArgs m{};
-    m.va = mw.va; m.qmeta = mw.qmeta; m.tab = mw.tab; m.cnt_ws = mw.cnt_ws; m.queue = mw.queue; m.queue_cnt = mw.queue_cnt;
-    m.queue_cap = mw.queue_cap; m.fallback = mw.fallback; m.vb = bf16 ? mw.vb : nullptr; m.rv = mw.rv; m.vc = mw.vc; m.qc = mw.qc;
+    m.va = mw.va; m.qmeta = mw.qmeta; m.tab = mw.tab; m.cnt_ws = mw.cnt_ws; m.amb = mw.amb; m.pairs_total = mw.pairs_total; m.wmax = mw.wmax;
+    m.fallback = mw.fallback; m.vb = bf16 ? mw.vb : nullptr; m.rv = mw.rv; m.vc = mw.vc; m.qc = mw.qc;
     {
         vfr::ProfScope prof(vfr::SITE_SCORE_PREP, st);
-        if (!bank_ready) {                   // bank side: mean, centred rows, squared norms, the largest norm (bf16: the rounded copy)
-            if (hipMemsetAsync(mw.rv, 0, 4, st) != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: hipMemsetAsync failed");
+        {
+            // bank side: mean, centred rows, squared norms, the largest norm (bf16: the rounded copy) -- recomputed unless the
+            // caller claims BANK_READY AND the bank still hashes to the signature stored with the products (score_mfma.h)
+            vfr::BankSig now{};
+            now.total_clips = total_clips; now.Nv = Nv; now.D = D; now.eps_bits = __builtin_bit_cast(unsigned, eps); now.has_bf16 = bf16 ? 1 : 0;
+            const int64_t nwords = (int64_t)total_clips * D;
+            int hb = (int)vfr::cdiv(nwords, 256 * 4 * 8);
+            hb = hb < 1 ? 1 : (hb > 2048 ? 2048 : hb);
+            hipLaunchKernelGGL(vfr::mfma_bank_hash_kernel, dim3((unsigned)hb), dim3(256), 0, st, reinterpret_cast<const unsigned *>(V), nwords,
+                               reinterpret_cast<const unsigned *>(clip_offsets), (int64_t)Nv + 1, mw.hash_now);
+            hipLaunchKernelGGL(vfr::mfma_bank_check_kernel, dim3(1), dim3(1), 0, st, mw.hash_now, now, bank_ready ? 1 : 0, mw.sig, mw.stale, mw.rv);
             hipLaunchKernelGGL(vfr::mfma_mean_partial_kernel, dim3((unsigned)mw.mean_blocks), dim3(1024), 0, st, V, total_clips, D, mw.mean_rows,
-                               mw.mean_partial);
-            hipLaunchKernelGGL(vfr::mfma_mean_final_kernel, dim3(1), dim3(1024), 0, st, mw.mean_partial, mw.mean_blocks, D, total_clips, mw.mu);
+                               mw.mean_partial, mw.stale);
+            hipLaunchKernelGGL(vfr::mfma_mean_final_kernel, dim3(1), dim3(1024), 0, st, mw.mean_partial, mw.mean_blocks, D, total_clips, mw.mu, mw.stale);
             hipLaunchKernelGGL(vfr::mfma_prep_v_kernel, dim3((unsigned)vfr::cdiv(total_clips, 4)), dim3(256), 0, st, V, total_clips, D, eps,
-                               mw.mu, mw.vc, mw.va, mw.rv, bf16 ? mw.vb : nullptr);
+                               mw.mu, mw.vc, mw.va, mw.rv, bf16 ? mw.vb : nullptr, mw.stale);
         }
         hipLaunchKernelGGL(vfr::mfma_prep_q_kernel, dim3((unsigned)vfr::cdiv(Nq, 16)), dim3(256), 0, st, Q, Nq, D, eps, mw.mu, mw.qc, mw.rv,
                            num_rank, rank_dist, mw.qmeta);
         if (num_rank > 0) {
             const dim3 tg((unsigned)vfr::cdiv(Nq * num_rank * NT, 256));
             if (NT == 6)
-                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<6>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0, mw.fallback);
+                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<6>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0, mw.fallback, mw.wmax);
             else
-                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<21>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0, mw.fallback);
+                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<21>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0, mw.fallback, mw.wmax);
         }
         if (k > 0) {
             if (thr_seed)
@@ -1816,12 +1828,12 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
     if (num_rank > 0 && !bf16) {
         vfr::ProfScope prof(vfr::SITE_SCORE_PAIRS, st);
         if (NT == 6)
-            hipLaunchKernelGGL((vfr::score_pairs_exact_kernel<6, 2>), dim3((unsigned)(g * c)), dim3(64), 0, st, Q, V, clip_offsets, moment_offsets,
+            hipLaunchKernelGGL((vfr::score_pairs_video_kernel<6, 2>), dim3((unsigned)Nv), dim3(64), 0, st, Q, V, clip_offsets, moment_offsets,
                                rank_dist, rank_idx, a, m);
         else
-            hipLaunchKernelGGL((vfr::score_pairs_exact_kernel<21, 2>), dim3((unsigned)(g * c)), dim3(64), 0, st, Q, V, clip_offsets, moment_offsets,
+            hipLaunchKernelGGL((vfr::score_pairs_video_kernel<21, 2>), dim3((unsigned)Nv), dim3(64), 0, st, Q, V, clip_offsets, moment_offsets,
                                rank_dist, rank_idx, a, m);
-        VFR_CHECK_LAUNCH("score_pairs_exact_kernel");
+        VFR_CHECK_LAUNCH("score_pairs_video_kernel");
     }
     {
         vfr::ProfScope prof(vfr::SITE_SCORE_FINISH, st);
@@ -1864,15 +1876,16 @@ int vfr_score_topk_mfma_stats(const void *workspace, int64_t Nq, int Nv, int tot
     VFR_REQUIRE(workspace && stats_host && Nq > 0 && Nv > 0, VFR_EINVAL, "vfr_score_topk_mfma_stats: bad argument");
     hipStream_t st = vfr::as_stream(stream);
     vfr::MfmaWs mw = vfr::carve_mfma(const_cast<void *>(workspace), Nq, Nv, total_clips, k);
-    std::vector<int> fb(mw.groups), qc(mw.tasks);
+    std::vector<int> fb(mw.groups);
+    unsigned long long np = 0;
     if (hipMemcpyAsync(fb.data(), mw.fallback, fb.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(qc.data(), mw.queue_cnt, qc.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&np, mw.pairs_total, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
         return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma_stats: copy failed");
-    int64_t nf = 0, np = 0;
+    int64_t nf = 0;
     for (int v : fb) nf += v != 0;
-    for (int v : qc) np += v;
-    stats_host[0] = mw.groups; stats_host[1] = nf; stats_host[2] = np; stats_host[3] = (int64_t)mw.tasks * mw.queue_cap;
+    // [3]: pairs the bitmap can mark (every (query, video) pair: the marking has no capacity limit)
+    stats_host[0] = mw.groups; stats_host[1] = nf; stats_host[2] = (int64_t)np; stats_host[3] = (int64_t)Nq * Nv;
     if (getenv("VFR_MFMA_DEBUG")) {
         float rv = 0, qm[4]; unsigned tab[2 * 21 * 4];
         (void)hipMemcpy(&rv, mw.rv, 4, hipMemcpyDeviceToHost);

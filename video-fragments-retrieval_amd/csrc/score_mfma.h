@@ -55,6 +55,7 @@ struct MfmaArgs {
     const float *va;                         // [total_clips] a_c
     const float4 *qmeta;                     // [Nq] {b_q, dfl, E2, R + |q|} (centred norms)
     const unsigned *tab;                     // [Nq][NR][NT][MF_TAB]
+    unsigned *wmax;                          // [Nq] widest window of the query over keys and span lengths (zeroed per call, atomicMax by the table pre-pass)
     unsigned long long *cnt_ws;              // [NR][Nq] rank counts of this call (committed to count_lt at the end)
     ulonglong2 *amb;                         // [Nv][groups] ambiguous pairs: bit l of .x / .y = query 64 g + l needs key 0 / 1 re-counted
     unsigned long long *pairs_total;         // [1] marked pairs re-scored exactly (statistics)
@@ -67,12 +68,60 @@ struct MfmaArgs {
 // ---------------------------------------------------------------------------------------------------------------------
 // pre-passes
 // ---------------------------------------------------------------------------------------------------------------------
+// Guard of VFR_MFMA_BANK_READY.  The bank-side products in the workspace (mu, centred rows, a_c, max norm, bf16 copy) are
+// only as good as the bank they were computed from.  Every pre-filter call hashes what the products depend on -- every
+// 32-bit word of V (each multiplied by an odd weight derived from its position, summed modulo 2^64: order-independent, so
+// the block partials can be added with atomics) and of the clip offsets -- and a one-thread kernel compares
+// {hash, total_clips, Nv, D, eps, bf16 copy present} with the signature the previous call left behind the products:
+//   * BANK_READY and equal      -> `stale` = 0: the bank pre-passes, which are always launched, return at once;
+//   * anything else             -> `stale` = 1: they recompute, and the new signature is stored.
+// No host decision, no synchronisation; 84 MB of V hash in ~20 us.  What is NOT covered: the caller's promise that the
+// product region of the workspace itself was not overwritten since that call.
+struct BankSig { unsigned long long hash; int total_clips, Nv, D; unsigned eps_bits; int has_bf16; int pad; };
+__global__ __launch_bounds__(256) void mfma_bank_hash_kernel(const unsigned *__restrict__ Vw, int64_t nwords,
+                                                             const unsigned *__restrict__ off_w, int64_t noff,
+                                                             unsigned long long *__restrict__ hash)
+{
+    __shared__ unsigned long long red[4];
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    unsigned long long h = 0ull;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < nwords; i += stride) {
+        if (i + 3 < nwords) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(Vw + i);
+            const unsigned long long p = (unsigned long long)i * 0x9E3779B97F4A7C15ull;
+            h += w.x * (p | 1ull) + w.y * ((p + 0x2545F4914F6CDD1Dull) | 1ull) + w.z * ((p ^ 0xD6E8FEB86659FD93ull) | 1ull) +
+                 w.w * ((p * 3ull + 0x632BE59BD9B4E019ull) | 1ull);
+        } else {
+            for (int64_t j2 = i; j2 < nwords; ++j2) h += Vw[j2] * ((((unsigned long long)j2 + 7ull) * 0xC2B2AE3D27D4EB4Full) | 1ull);
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < noff; i += (int64_t)gridDim.x * 256)
+        h += off_w[i] * ((((unsigned long long)i + 11ull) * 0x165667B19E3779F9ull) | 1ull);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) h += __shfl_xor(h, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(hash, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void mfma_bank_check_kernel(const unsigned long long *__restrict__ hash_now, BankSig now, int ready_claimed,
+                                       BankSig *__restrict__ stored, int *__restrict__ stale, float *__restrict__ rv)
+{
+    now.hash = *hash_now;
+    const BankSig old = *stored;
+    const bool same = ready_claimed && old.hash == now.hash && old.total_clips == now.total_clips && old.Nv == now.Nv && old.D == now.D &&
+                      old.eps_bits == now.eps_bits && old.has_bf16 >= now.has_bf16;
+    *stale = same ? 0 : 1;
+    if (!same) { *stored = now; *rv = 0.0f; }                             // (rv: the max-norm accumulator of mfma_prep_v_kernel)
+}
+
+
 // mean clip embedding mu [D] (D <= 128), two deterministic stages: 1024-thread blocks sum a slice of rows (thread = column x
 // row phase, fp64), then one 1024-thread block adds the per-block partials (8 slices per column)
 __global__ __launch_bounds__(1024) void mfma_mean_partial_kernel(const float *__restrict__ V, int total_clips, int D, int rows_per_block,
-                                                                 double *__restrict__ partial)
+                                                                 double *__restrict__ partial, const int *__restrict__ stale)
 {
     __shared__ double red[1024];
+    if (!*stale) return;                                                  // the products in the workspace are this bank's
     const int k = threadIdx.x & 127, ph = threadIdx.x >> 7;              // column, row phase (8)
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
@@ -90,9 +139,10 @@ __global__ __launch_bounds__(1024) void mfma_mean_partial_kernel(const float *__
     }
 }
 __global__ __launch_bounds__(1024) void mfma_mean_final_kernel(const double *__restrict__ partial, int nblocks, int D, int total_clips,
-                                                               float *__restrict__ mu)
+                                                               float *__restrict__ mu, const int *__restrict__ stale)
 {
     __shared__ double red[1024];
+    if (!*stale) return;
     const int k = threadIdx.x & 127, sl = threadIdx.x >> 7;
     double acc = 0.0;
     if (k < D)
@@ -112,8 +162,9 @@ __global__ __launch_bounds__(1024) void mfma_mean_final_kernel(const double *__r
 __global__ __launch_bounds__(256) void mfma_prep_v_kernel(const float *__restrict__ V, int total_clips, int D, float eps,
                                                           const float *__restrict__ mu, float *__restrict__ vc,
                                                           float *__restrict__ va, float *__restrict__ rv,
-                                                          unsigned short *__restrict__ vb)
+                                                          unsigned short *__restrict__ vb, const int *__restrict__ stale)
 {
+    if (!*stale) return;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= total_clips) return;
@@ -181,7 +232,7 @@ __global__ __launch_bounds__(256) void mfma_prep_q_kernel(const float *__restric
 template <int NT>
 __global__ __launch_bounds__(256) void mfma_prep_tab_kernel(int64_t Nq, int NR, const float *__restrict__ rank_dist,
                                                             const float4 *__restrict__ qmeta, unsigned *__restrict__ tab,
-                                                            int bf16_mode, int *__restrict__ fallback)
+                                                            int bf16_mode, int *__restrict__ fallback, unsigned *__restrict__ wmax)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= Nq * NR * NT) return;
@@ -214,6 +265,7 @@ __global__ __launch_bounds__(256) void mfma_prep_tab_kernel(int64_t Nq, int NR, 
     // its ambiguous pairs cost more.  A key distance so small that no margin exists (delta = inf: the window is the whole
     // float range) sends the query's group to the exact kernels right away; the pre-filter kernel returns at once for it.
     if (!bf16_mode && HIW - LOW >= MF_WIDTH_MAX) fallback[q >> 6] = 1;
+    if (!bf16_mode && HIW - LOW > 1023u) atomicMax(wmax + q, HIW - LOW);   // (narrower windows need no shift: no atomic in the common case)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -289,14 +341,7 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
 #pragma unroll
     for (int w = 0; w < NW; ++w) wpk[w] = 0u;
     if (NR > 0 && !BF16) {
-        unsigned wmax = 0u;
-#pragma unroll
-        for (int L = 1; L <= NT; ++L)
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const unsigned w_ = active ? m.tab[(((active ? qi : 0) * NR + r) * NT + (L - 1)) * MF_TAB + 3] : 0u;
-                wmax = w_ > wmax ? w_ : wmax;
-            }
+        const unsigned wmax = active ? m.wmax[qi] : 0u;                   // 0: every window of the query fits 10 bits
         wide = wmax >= MF_WIDTH_MAX;                                      // (its group is flagged by the table pre-pass)
         const int bits = 32 - __builtin_clz(wmax | 1u);
         wsh = bits > 10 ? (unsigned)(bits - 10) : 0u;
@@ -592,7 +637,7 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
 // from per-lane LDS reads: ~4.5 pairs shared a video, 75 % of the lanes worked and the kernel waited on LDS -- 2.2 ms for the
 // 7 % of pairs of the bench corpus.)
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int PV_LIST = 4096;                // list entries per 64-group chunk (every query of the chunk marked)
+constexpr int PV_LIST = 1024;                // list window: entries expanded at a time (a 64-group chunk rarely marks more)
 template <int NT, int NR>
 __global__ __launch_bounds__(64) void score_pairs_video_kernel(const float *__restrict__ Qp, const float *__restrict__ Vp,
                                                                const int32_t *__restrict__ clip_off,
@@ -602,6 +647,8 @@ __global__ __launch_bounds__(64) void score_pairs_video_kernel(const float *__re
 {
     static_assert(NR == 2, "two rank keys per query (the bitmap holds one mask per key)");
     constexpr int ROW4 = FAST_D / 4, NLD = (NT * ROW4 + 63) / 64;
+    // 16 KB of LDS and ~160 VGPRs: ten waves per CU -- the kernel is a chain of dependent gathers (bitmap -> query rows ->
+    // bound table) around 7 us of arithmetic per batch, and lives on the waves it has in flight
     __shared__ __attribute__((aligned(16))) float vst[NT * FAST_D];     // clip rows of this video
     __shared__ unsigned short list[PV_LIST];                             // (group in chunk) << 8 | lane bit << 2 | key mask
     __shared__ float dx[64 * (NT + 1)];                                  // tie walk only: exact distances [pair][clip]
@@ -609,20 +656,11 @@ __global__ __launch_bounds__(64) void score_pairs_video_kernel(const float *__re
     const int groups = a.num_groups;
     const int c0 = clip_off[v], n = clip_off[v + 1] - c0;
     const int64_t mbase = mom_off[v];
-    {
-        const float4 *V4 = reinterpret_cast<const float4 *>(Vp);
-        const int64_t v4_end = (int64_t)a.total_clips * ROW4;
-#pragma unroll
-        for (int t = 0; t < NLD; ++t) {
-            const int idx = lane + 64 * t;
-            const int64_t g4 = (int64_t)c0 * ROW4 + idx;
-            if (idx < NT * ROW4) reinterpret_cast<float4 *>(vst)[idx] = g4 < v4_end ? V4[g4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
+    bool staged = false;
     const float2v e2 = {a.eps, a.eps};
     unsigned long long npairs = 0;
     for (int gb = 0; gb < groups; gb += 64) {
-        // ---- expand the bitmaps of groups gb .. gb + 63 ----
+        // ---- the bitmaps of groups gb .. gb + 63 (lane = group) ----
         const int g = gb + lane;
         ulonglong2 mm = ulonglong2{0ull, 0ull};
         if (g < groups && !m.fallback[g]) mm = m.amb[(size_t)v * groups + g];
@@ -633,117 +671,186 @@ __global__ __launch_bounds__(64) void score_pairs_video_kernel(const float *__re
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); incl += lane >= o ? t : 0; }
         const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total == 0) continue;
-        __builtin_amdgcn_s_waitcnt(0xC07F);                              // the previous chunk's list reads are done
-        {
-            int pos = incl - c;
-            unsigned long long rest = any;
-            while (rest) {
-                const int b = __builtin_ctzll(rest);
-                rest &= rest - 1ull;
-                list[pos++] = (unsigned short)((lane << 8) | (b << 2) | (unsigned)((mm.x >> b) & 1ull) | ((unsigned)((mm.y >> b) & 1ull) << 1));
-            }
-        }
         npairs += (unsigned long long)total;
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-        for (int base = 0; base < total; base += 64) {
-            const bool have = base + lane < total;
-            const unsigned ent = list[have ? base + lane : base];
-            const unsigned rmask = have ? (ent & 3u) : 0u;
-            int64_t qi = (int64_t)(gb + (int)(ent >> 8)) * 64 + ((ent >> 2) & 63u);
-            qi = qi < a.Nq ? qi : a.Nq - 1;
-            // ---- the query row, then the canonical chains (clip rows broadcast from LDS) ----
-            float2v qp[FAST_D / 2];
+        if (!staged) {                                                   // a video nobody marked costs one bitmap read
+            const float4 *V4 = reinterpret_cast<const float4 *>(Vp);
+            const int64_t v4_end = (int64_t)a.total_clips * ROW4;
+#pragma unroll
+            for (int t = 0; t < NLD; ++t) {
+                const int idx = lane + 64 * t;
+                const int64_t g4 = (int64_t)c0 * ROW4 + idx;
+                if (idx < NT * ROW4) reinterpret_cast<float4 *>(vst)[idx] = g4 < v4_end ? V4[g4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            staged = true;
+        }
+        for (int win = 0; win < total; win += PV_LIST) {
+            // ---- expand: every lane writes the set bits of its group that fall into the window ----
+            __builtin_amdgcn_s_waitcnt(0xC07F);                          // the previous window's list reads are done
+            __builtin_amdgcn_wave_barrier();
             {
+                int pos = incl - c - win;
+                unsigned long long rest = any;
+                while (rest && pos < PV_LIST) {
+                    const int b = __builtin_ctzll(rest);
+                    rest &= rest - 1ull;
+                    if (pos >= 0)
+                        list[pos] = (unsigned short)((lane << 8) | (b << 2) | (unsigned)((mm.x >> b) & 1ull) | ((unsigned)((mm.y >> b) & 1ull) << 1));
+                    ++pos;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            const int wtotal = total - win < PV_LIST ? total - win : PV_LIST;
+            for (int base = 0; base < wtotal; base += 64) {
+                const bool have = base + lane < wtotal;
+                const unsigned ent = list[have ? base + lane : base];
+                const unsigned rmask = have ? (ent & 3u) : 0u;
+                int64_t qi = (int64_t)(gb + (int)(ent >> 8)) * 64 + ((ent >> 2) & 63u);
+                qi = qi < a.Nq ? qi : a.Nq - 1;
+                // ---- the canonical chains (clip rows broadcast from LDS), the query row in two parts of 13 and 12 float4: every
+                // chain still runs k-ascending -- its accumulator waits in LDS between the parts -- and the row costs 52 registers
+                // instead of 100.  Three clips at a time (a run-time loop: the code stays small), software-pipelined over k like
+                // score_fast_kernel: the 3 broadcast reads of slice j4 + 1 are issued (and pinned by the sched_barrier) before the
+                // 24 VALU ops of slice j4 -- left to the compiler the reads sat two instructions ahead of their use ----
                 const float4 *q4 = reinterpret_cast<const float4 *>(Qp + qi * FAST_D);
+                float *dl = dx + lane * (NT + 1);                        // this lane's partial sums, then distances
+                const int ng = (n + 2) / 3;
+                auto chain_part = [&](auto lo_c, auto hi_c, auto first_c) {
+                    constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value, NC = 3;
+                    constexpr bool FIRST = decltype(first_c)::value;
+                    float2v qp[2 * (HI - LO)];
 #pragma unroll
-                for (int j4 = 0; j4 < ROW4; ++j4) {
-                    const float4 y = q4[j4];
-                    qp[2 * j4] = float2v{y.x, y.y}; qp[2 * j4 + 1] = float2v{y.z, y.w};
-                }
-            }
-            float d[NT];
-#pragma unroll
-            for (int cc = 0; cc < NT; ++cc) {
-                d[cc] = __builtin_inff();
-                if (cc < n) {                                            // wave-uniform
-                    const float4 *v4 = reinterpret_cast<const float4 *>(vst + cc * FAST_D);
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int j4 = 0; j4 < ROW4; ++j4) {
-                        const float4 x = v4[j4];
-                        const float2v d01 = (float2v{x.x, x.y} - qp[2 * j4]) + e2;
-                        const float2v d23 = (float2v{x.z, x.w} - qp[2 * j4 + 1]) + e2;
-                        acc = __builtin_fmaf(d01.x, d01.x, acc);
-                        acc = __builtin_fmaf(d01.y, d01.y, acc);
-                        acc = __builtin_fmaf(d23.x, d23.x, acc);
-                        acc = __builtin_fmaf(d23.y, d23.y, acc);
+                    for (int j4 = LO; j4 < HI; ++j4) {
+#ifdef VFR_PV_SKIP_QLOAD
+                        const float4 y = make_float4((float)(lane + j4), 1.0f, 2.0f, (float)qi);   // timing experiment: no gather
+#else
+                        const float4 y = q4[j4];
+#endif
+                        qp[2 * (j4 - LO)] = float2v{y.x, y.y}; qp[2 * (j4 - LO) + 1] = float2v{y.z, y.w};
                     }
-                    d[cc] = __builtin_sqrtf(acc);
-                }
-            }
-            // ---- exact triangle: bits(sum) against the table's exclusive bounds (score < x <=> bits < LOX) ----
-            const unsigned *tq = m.tab + (size_t)qi * NR * NT * MF_TAB;
-            int cntr[NR] = {0, 0};
-            bool tie = false;
-            float sums[NT];
+#pragma nounroll
+                    for (int g3 = 0; g3 < ng; ++g3) {
+                        const float4 *vt = reinterpret_cast<const float4 *>(vst) + g3 * NC * ROW4;
+                        float ac[NC];
 #pragma unroll
-            for (int L = 1; L <= NT; ++L) {
-                unsigned lox[NR], dhl[NR], below[NR], umin[NR];
+                        for (int i = 0; i < NC; ++i) ac[i] = FIRST ? 0.0f : dl[g3 * NC + i];
+                        float4 cur[NC], nxt[NC];
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const uint2 e = *reinterpret_cast<const uint2 *>(tq + (r * NT + (L - 1)) * MF_TAB);
-                    lox[r] = e.x; dhl[r] = e.y - e.x; below[r] = 0u; umin[r] = 0xFFFFFFFFu;
-                }
+                        for (int i = 0; i < NC; ++i) cur[i] = vt[i * ROW4 + LO];
 #pragma unroll
-                for (int s2 = 0; s2 + L <= NT; ++s2) {
-                    const float de = d[s2 + L - 1];
-                    const float sum = L == 1 ? de : sums[s2] + de;
-                    sums[s2] = sum;
-                    const unsigned sb = __float_as_uint(sum);
+                        for (int j4 = LO; j4 < HI; ++j4) {
+                            if (j4 + 1 < HI) {
+#pragma unroll
+                                for (int i = 0; i < NC; ++i) nxt[i] = vt[i * ROW4 + j4 + 1];
+                            }
+                            // (the first slice also waits for the query part: vmcnt 0; afterwards only LDS is outstanding)
+                            if (j4 == LO) __builtin_amdgcn_s_waitcnt(0x0070 | (NC << 8));
+                            else if (j4 + 1 < HI) __builtin_amdgcn_s_waitcnt(0xC07F | (NC << 8));
+                            else __builtin_amdgcn_s_waitcnt(0xC07F);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int i = 0; i < NC; ++i) {
+#ifdef VFR_PV_SKIP_CHAIN
+                                ac[i] += cur[i].x + qp[2 * (j4 - LO)].x;   // timing experiment: no chain
+#else
+                                const float2v d01 = (float2v{cur[i].x, cur[i].y} - qp[2 * (j4 - LO)]) + e2;
+                                const float2v d23 = (float2v{cur[i].z, cur[i].w} - qp[2 * (j4 - LO) + 1]) + e2;
+                                ac[i] = __builtin_fmaf(d01.x, d01.x, ac[i]);
+                                ac[i] = __builtin_fmaf(d01.y, d01.y, ac[i]);
+                                ac[i] = __builtin_fmaf(d23.x, d23.x, ac[i]);
+                                ac[i] = __builtin_fmaf(d23.y, d23.y, ac[i]);
+#endif
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int i = 0; i < NC; ++i) cur[i] = nxt[i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < NC; ++i) dl[g3 * NC + i] = HI == ROW4 ? __builtin_sqrtf(ac[i]) : ac[i];
+                    }
+                };
+                chain_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 13>{}, std::true_type{});
+                chain_part(std::integral_constant<int, 13>{}, std::integral_constant<int, ROW4>{}, std::false_type{});
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                float d[NT];
+#pragma unroll
+                for (int cc = 0; cc < NT; ++cc) d[cc] = cc < n ? dl[cc] : __builtin_inff();
+                // ---- exact triangle: bits(sum) against the table's exclusive bounds (score < x <=> bits < LOX) ----
+                // (the 42 bound pairs are requested here, after the query row's 100 registers are dead: hoisted above the chains
+                // they would not fit)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned *tq = m.tab + (size_t)qi * NR * NT * MF_TAB;
+                int cntr[NR] = {0, 0};
+                bool tie = false;
+                float sums[NT];
+#pragma unroll
+                for (int L = 1; L <= NT; ++L) {
+                    unsigned lox[NR], dhl[NR], below[NR], umin[NR];
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
-                        const unsigned u = sb - lox[r];
-                        below[r] = __builtin_amdgcn_alignbit(below[r], u, 31);
-                        umin[r] = u < umin[r] ? u : umin[r];
+#ifdef VFR_PV_SKIP_TAB
+                        const uint2 e = make_uint2(0x3F800000u + (unsigned)(L * 65536 + r), 0x3F800000u + (unsigned)(L * 65536 + r));   // timing experiment
+#else
+                        const uint2 e = *reinterpret_cast<const uint2 *>(tq + (r * NT + (L - 1)) * MF_TAB);
+#endif
+                        lox[r] = e.x; dhl[r] = e.y - e.x; below[r] = 0u; umin[r] = 0xFFFFFFFFu;
                     }
-                }
+#ifdef VFR_PV_SKIP_TRI
+                    if (L > 1) continue;                                 // timing experiment: one level of the triangle
+#endif
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    cntr[r] += __builtin_popcount(below[r]);
-                    tie = tie || umin[r] < dhl[r];
-                }
-            }
-            if (__ballot(tie && rmask != 0u)) {
-                // bits(sum) inside [LOX, HIX) somewhere: score == a key distance; this lane's video once more with the quotients,
-                // ties broken by moment id (the distances go through LDS: the walk indexes them dynamically)
+                    for (int s2 = 0; s2 + L <= NT; ++s2) {
+                        const float de = d[s2 + L - 1];
+                        const float sum = L == 1 ? de : sums[s2] + de;
+                        sums[s2] = sum;
+                        const unsigned sb = __float_as_uint(sum);
 #pragma unroll
-                for (int cc = 0; cc < NT; ++cc) dx[lane * (NT + 1) + cc] = d[cc];
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                if (tie) {
-                    float xk[NR];
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) xk[r] = rank_dist[r * a.Nq + qi];
-#pragma nounroll
-                    for (int s2 = 0; s2 < n; ++s2) {
-                        float sum = 0.0f;
-#pragma nounroll
-                        for (int e = s2; e < n; ++e) {
-                            const float de = dx[lane * (NT + 1) + e];
-                            sum = e == s2 ? de : sum + de;
-                            const float sc = sum / (float)(e - s2 + 1);
-                            const unsigned id = (unsigned)(a.id_base + mbase + moment_index(n, s2, e));
-#pragma unroll
-                            for (int r = 0; r < NR; ++r)
-                                if (sc == xk[r] && id < (unsigned)rank_idx[r * a.Nq + qi]) cntr[r] += 1;
+                        for (int r = 0; r < NR; ++r) {
+                            const unsigned u = sb - lox[r];
+                            below[r] = __builtin_amdgcn_alignbit(below[r], u, 31);
+                            umin[r] = u < umin[r] ? u : umin[r];
                         }
                     }
-                }
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-            }
 #pragma unroll
-            for (int r = 0; r < NR; ++r)
-                if (((rmask >> r) & 1u) && cntr[r]) atomicAdd(m.cnt_ws + r * a.Nq + qi, (unsigned long long)cntr[r]);
+                    for (int r = 0; r < NR; ++r) {
+                        cntr[r] += __builtin_popcount(below[r]);
+                        tie = tie || umin[r] < dhl[r];
+                    }
+                }
+                if (__ballot(tie && rmask != 0u)) {
+                    // bits(sum) inside [LOX, HIX) somewhere: score == a key distance (every query's own video gets here: the key
+                    // IS one of its moments); this lane's video once more with the quotients, ties broken by moment id (the
+                    // distances go through LDS: the walk indexes them dynamically)
+#pragma unroll
+                    for (int cc = 0; cc < NT; ++cc) dx[lane * (NT + 1) + cc] = d[cc];
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                    if (tie) {
+                        float xk[NR];
+                        unsigned ik[NR];
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) { xk[r] = rank_dist[r * a.Nq + qi]; ik[r] = (unsigned)rank_idx[r * a.Nq + qi]; }
+#pragma nounroll
+                        for (int s2 = 0; s2 < n; ++s2) {
+                            float sum = 0.0f;
+#pragma nounroll
+                            for (int e = s2; e < n; ++e) {
+                                const float de = dx[lane * (NT + 1) + e];
+                                sum = e == s2 ? de : sum + de;
+                                const float sc = sum / (float)(e - s2 + 1);
+                                const unsigned id = (unsigned)(a.id_base + mbase + moment_index(n, s2, e));
+#pragma unroll
+                                for (int r = 0; r < NR; ++r)
+                                    if (sc == xk[r] && id < ik[r]) cntr[r] += 1;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                }
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    if (((rmask >> r) & 1u) && cntr[r]) atomicAdd(m.cnt_ws + r * a.Nq + qi, (unsigned long long)cntr[r]);
+            }
         }
     }
     if (lane == 0 && npairs) atomicAdd(m.pairs_total, npairs);

@@ -92,13 +92,41 @@ def _all_gather_rows(dist, out, mine):
     Which form is used is decided from what the ``dist`` object offers -- the same on every rank, never from an exception
     at call time (a rank that fell back alone would issue a different collective than its peers and hang them): the list
     form is only for the thread-rank / provider stand-ins of the tests, which have no ``all_gather_into_tensor``."""
-    fn = getattr(dist, "all_gather_into_tensor", None)
-    if fn is not None:
+    if _gather_form(dist) == "tensor":
         # concatenated form (rank g's rows at [g * rows, (g + 1) * rows)): the same memory as out[g], and the shape both
         # the RCCL and the gloo process groups accept
-        fn(out.view((out.shape[0] * mine.shape[0],) + tuple(mine.shape[1:])) if mine.dim() >= 1 else out, mine)
+        dist.all_gather_into_tensor(out.view((out.shape[0] * mine.shape[0],) + tuple(mine.shape[1:])) if mine.dim() >= 1 else out, mine)
     else:
         dist.all_gather([out[g] for g in range(out.shape[0])], mine)
+
+
+_GATHER_FORM = {}
+
+
+def _gather_form(dist) -> str:
+    """"tensor" or "list", chosen ONCE per provider from rank-uniform facts: the stand-ins of the tests have no
+    ``all_gather_into_tensor``; for ``torch.distributed`` the backend decides -- RCCL ("nccl") always has the tensor form, gloo
+    only in builds whose ProcessGroupGloo implements ``_allgather_base`` (probed once with a 1-element collective whose
+    outcome is MIN-reduced over the ranks, so a build in which some rank refuses makes EVERY rank take the list form)."""
+    backend = str(dist.get_backend()).lower() if hasattr(dist, "get_backend") else None
+    key = (id(dist), backend)
+    form = _GATHER_FORM.get(key)
+    if form is None:
+        if getattr(dist, "all_gather_into_tensor", None) is None:
+            form = "list"
+        elif backend != "gloo":
+            form = "tensor"
+        else:
+            world = dist.get_world_size()
+            ok = torch.ones(1, dtype=torch.int32)
+            try:
+                dist.all_gather_into_tensor(torch.zeros(world, dtype=torch.int32), torch.zeros(1, dtype=torch.int32))
+            except (RuntimeError, NotImplementedError):
+                ok.zero_()                                   # refused before anything was sent: the ranks still agree below
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            form = "tensor" if int(ok[0]) else "list"
+        _GATHER_FORM[key] = form
+    return form
 
 
 @dataclass
@@ -282,6 +310,19 @@ def gt_label_table(times, counts_own, thresholds, strict=True):
         # [0, T)^2 once per clip count, then every query just gathers its annotators' rows
         T = max(int(n), int(tq.max()) + 1 if tq.size else 0)
         lo = int(tq.min()) if tq.size else 0
+        if T - lo > 64:
+            # spans far outside the clip range (a foreign annotation file): the (T - lo)^2 table would be quadratic in the
+            # largest index; the per-query broadcast form is O(nq A M) like the reference's loop
+            s, e = mom[None, None, :, 0], mom[None, None, :, 1]
+            ts, te = tq[:, :, 0:1], tq[:, :, 1:2]
+            inter = np.maximum(np.minimum(te, e) + 1 - np.maximum(ts, s), 0)
+            union = np.maximum(te, e) + 1 - np.minimum(ts, s)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                iou = inter / union                                                   # [nq_n, A, M] float64
+            for r, thr in enumerate(thresholds):
+                hit = ((iou > thr) if strict else (iou >= thr)) & valid[q]
+                labels[r, q, :len(mom)] = hit.sum(axis=1) >= 2
+            continue
         ts, te = np.meshgrid(np.arange(lo, T), np.arange(lo, T), indexing="ij")
         ts, te = ts[:, :, None], te[:, :, None]
         s, e = mom[None, None, :, 0], mom[None, None, :, 1]

@@ -132,6 +132,37 @@ def vgg_weights(cfg, in_hw, fc_dim: int, seed: int = 123):
     return conv_w, conv_b, fc6, fc7
 
 
+def resnet_weights(blocks=(3, 8, 36, 3), width: int = 64, seed: int = 123):
+    """Random torchvision-style ``state_dict`` (numpy float32) for a Bottleneck ResNet (``resnet152`` = blocks (3, 8, 36, 3),
+    width 64): He-scaled convolutions, BatchNorm running statistics away from (0, 1), and a small gamma on every block's last
+    BatchNorm so 50 residual additions with random weights stay O(1)."""
+    rs = np.random.RandomState(seed + 6)
+    sd = {}
+
+    def conv(name, cout, cin, k):
+        sd[name + ".weight"] = (rs.randn(cout, cin, k, k) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32)
+
+    def bn(name, c, gamma_scale=1.0):
+        sd[name + ".weight"] = (rs.uniform(0.5, 1.0, c) * gamma_scale).astype(np.float32)
+        sd[name + ".bias"] = (rs.randn(c) * 0.05).astype(np.float32)
+        sd[name + ".running_mean"] = (rs.randn(c) * 0.1).astype(np.float32)
+        sd[name + ".running_var"] = rs.uniform(0.5, 1.5, c).astype(np.float32)
+
+    conv("conv1", width, 3, 7); bn("bn1", width)
+    cin = width
+    for li, nb in enumerate(blocks):
+        mid = width * 2 ** li
+        for b in range(nb):
+            pre = f"layer{li + 1}.{b}"
+            conv(pre + ".conv1", mid, cin, 1); bn(pre + ".bn1", mid)
+            conv(pre + ".conv2", mid, mid, 3); bn(pre + ".bn2", mid)
+            conv(pre + ".conv3", 4 * mid, mid, 1); bn(pre + ".bn3", 4 * mid, 0.3)
+            if b == 0:
+                conv(pre + ".downsample.0", 4 * mid, cin, 1); bn(pre + ".downsample.1", 4 * mid)
+            cin = 4 * mid
+    return sd
+
+
 def ranking_batch(seed: int, P: int = 96, Nn: int = 80, S: int = 16, D: int = 100):
     """Seeded stand-in for one triplet batch of ``Trainer.train_epoch`` (``model/main.py:48-61``): embeddings ~ N(0, 0.1),
     masks = sorted sample ids covering every sample.  -> posit [P,D], intra [Nn,D], inter [P,D], lang [S,D], maskp, maskn."""
