@@ -214,6 +214,18 @@ int vfr_vgg_fc7_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *
                     const float *fc6_b, const float *fc7_w, const float *fc7_b, int fc_dim, float *out,
                     void *workspace, size_t workspace_bytes, vfr_stream_t stream);
 
+/* ---- f4  ResNet-152 variant of the extractor: torchvision resnet152 without its fc head, get_rgb_features.py:127-131
+ * (conv1 / bn1 / relu / maxpool, Bottleneck layers, global average pool) -> out [T, 32 * width] (2048 at width 64).
+ * blocks_host [4] = Bottleneck blocks per layer ({3, 8, 36, 3}); width = 64.  conv_w_host / bn_host: HOST arrays of DEVICE
+ * pointers, one per convolution in EXECUTION order -- the stem, then per block conv1 (1x1), conv2 (3x3, carries the
+ * stride), conv3 (1x1) and, for the first block of a layer, the 1x1 downsample convolution: conv weight [Cout, Cin, k, k]
+ * (torchvision layout) and its BatchNorm as one packed [4, Cout] tensor (weight, bias, running_mean, running_var).  Eval-mode
+ * BatchNorm is folded into the convolution (csrc/resnet.hip); bn_eps = 1e-5 for torchvision's modules.                    */
+size_t vfr_resnet_pool_workspace_bytes(int T, int H, int W, const int *blocks_host, int width);
+int vfr_resnet_pool_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *blocks_host, int width,
+                        const float *const *conv_w_host, const float *const *bn_host, float bn_eps, float *out, void *workspace,
+                        size_t workspace_bytes, vfr_stream_t stream);
+
 /* ---- f2  training / test loss: Trainer.ranking_loss, model/main.py:214-232 (called from train_epoch :63 and
  * test_epoch :102).  posit, inter [P,D], intra [Nn,D], lang [S,D]; maskp [P], maskn [Nn] int64 sample ids (rows whose id
  * is outside [0,S) belong to no sample).  loss[0] = sum_i relu(c_posit - c_intra + b) + lamb*relu(c_posit - c_inter + b),

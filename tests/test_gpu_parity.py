@@ -1094,3 +1094,62 @@ def test_mfma_prefilter_centres_offset_embeddings(vfr):
     st = vfr.score_mfma_stats(ws, nq, bank, k)
     assert st["fallback_groups"] == 0 and st["exact_pair_fraction"] < 0.3, st
     assert torch.equal(i0, i1) and torch.equal(d0, d1) and torch.equal(c0, c1) and bool((c0[0] == 30).all())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f4: the ResNet-152 variant of the extractor (get_rgb_features.py:127-131)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,blocks,width,T", [((64, 64), (1, 2, 2, 1), 8, 3), ((96, 80), (2, 1, 3, 2), 4, 2), ((64, 96), (1, 1, 1, 1), 32, 5),
+                                               ((224, 224), (1, 1, 2, 1), 16, 2)])
+def test_resnet_stack_bit_exact_reduced(vfr, oracle, hw, blocks, width, T):
+    """vfr_resnet_pool_f32 == the oracle bit for bit on reduced stacks that reach every layer form: the 7x7/2 stem through
+    im2col, 3x3/2 max-pool, 1x1 dense GEMMs, the 3x3 implicit-GEMM loader (stride 1) and im2col (stride 2), downsample branches of
+    stride 1 and 2, the residual epilogue, the global average; widths below and above one MFMA tile, odd spatial sizes."""
+    H, W = hw
+    frames = synth.frames_u8(T, H, W, seed=21)
+    sd = synth.resnet_weights(blocks, width, seed=21)
+    want = oracle.resnet_pool(frames, sd, blocks, width)
+    got = vfr.resnet_pool(dev(frames), vfr.resnet_pack(sd, blocks, width, DEV), blocks, width)
+    assert got.shape == (T, 32 * width) and same(got, want)
+
+
+@pytest.mark.gpu
+def test_resnet152_full_size_bit_exact_and_torch_fixture(vfr, oracle, golden):
+    """f4 at FULL size: ResNet-152 (3 / 8 / 36 / 3, width 64, 224x224): frame 0 == the oracle bit for bit, both frames == fixture
+    G12 (the same network from torch.nn modules) to 1e-4 of the activation scale; a pass over 70 frames (two chunks of the frame
+    loop) reproduces the two-frame result row for row."""
+    blocks, width = (3, 8, 36, 3), 64
+    sd = synth.resnet_weights(blocks, width, seed=12)
+    frames = synth.frames_u8(2, 224, 224, seed=12)
+    packed = vfr.resnet_pack(sd, blocks, width, DEV)
+    got = vfr.resnet_pool(dev(frames), packed)
+    want = golden("g12_resnet_full.npz")["pooled"]
+    assert got.shape == (2, 2048)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+    assert same(got[:1], oracle.resnet_pool(frames[:1], sd))
+    many = np.concatenate([frames] * 35)
+    got70 = vfr.resnet_pool(dev(many), packed)
+    assert torch.equal(got70[0::2], got[0:1].expand(35, -1)) and torch.equal(got70[1::2], got[1:2].expand(35, -1))
+
+
+@pytest.mark.gpu
+def test_extractor_resnet152_variant_front_end(vfr, oracle, tmp_path):
+    """features.extract_dataset(model_type="resnet152"): frame selection + the ResNet stack + resnet152_ft_<video>.npy files the
+    dataset side pools (model/data.py:22: FEATURE_DIM['resnet152'] = 32 * width here)."""
+    from vfr_amd import features
+    blocks, width = (1, 1, 1, 1), 8
+    sd = synth.resnet_weights(blocks, width, seed=9)
+    packed = vfr.resnet_pack(sd, blocks, width, DEV)
+    rs = np.random.RandomState(5)
+    clips = {"a": (rs.randint(0, 256, (150, 32, 32, 3)).astype(np.uint8), 5.0, 6), "b": (rs.randint(0, 256, (250, 32, 32, 3)).astype(np.uint8), 25.0, 2)}
+    info = [dict(video=k, num_segments=v[2]) for k, v in clips.items()] + [dict(video="broken", num_segments=6)]
+    decoder = lambda video, nseg: (None, 0) if video == "broken" else clips[video][:2]
+    ft = tmp_path / "features_resnet152"
+    written, missed = features.extract_dataset(info, decoder, ft, packed, model_type="resnet152", cfg=(blocks, width),
+                                               missed_path=tmp_path / "missed.json")
+    assert written == ["a", "b"] and missed == ["broken"]
+    for name, (frames, fps, nseg) in clips.items():
+        got = np.load(ft / f"resnet152_ft_{name}.npy")
+        mask = oracle.frame_sample_indices(len(frames), fps, nseg)
+        assert np.array_equal(got, oracle.resnet_pool(frames[mask], sd, blocks, width)), name

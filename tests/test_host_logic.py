@@ -420,7 +420,7 @@ def test_extract_dataset_resume_and_missed_bookkeeping(tmp_path, monkeypatch):
     from vfr_amd import features
     calls = []
 
-    def fake_extract(frames, fps, nseg, weights, cfg=None):
+    def fake_extract(frames, fps, nseg, weights, cfg=None, model_type="vgg19"):
         calls.append((len(frames), fps, nseg))
         return torch.full((len(features.sample_frames(len(frames), fps, nseg)), 4), float(nseg))
     monkeypatch.setattr(features, "extract_video", fake_extract)
@@ -435,5 +435,9 @@ def test_extract_dataset_resume_and_missed_bookkeeping(tmp_path, monkeypatch):
     assert written == ["v0", "v4"] and missed == ["v2", "v3"] and json.loads(missed_file.read_text()) == ["v2", "v3"]
     assert np.load(ft / "vgg19_ft_v0.npy").shape == (125, 4) and np.load(ft / "vgg19_ft_v1.npy").shape == (3, 4)
     assert calls == [(625, 25.0, 5), (625, 25.0, 5)]
-    with pytest.raises(NotImplementedError):
-        features.extract_dataset(info, decoder, ft, None, model_type="resnet152", missed_path=missed_file)
+    # the resnet152 variant (get_rgb_features.py:127-131) keeps its own file prefix: nothing of the vgg19 run counts as done
+    calls.clear()
+    written, _ = features.extract_dataset(info, decoder, ft, None, model_type="resnet152", missed_path=missed_file)
+    assert written == ["v0", "v1", "v4"] and (ft / "resnet152_ft_v1.npy").exists() and len(calls) == 3
+    with pytest.raises(ValueError):
+        features.extract_dataset(info, decoder, ft, None, model_type="resnet50", missed_path=missed_file)

@@ -51,3 +51,55 @@ def test_oracle_vgg_full_size_frame_matches_torch_modules(oracle, golden):
     got = oracle.vgg_fc7(synth.frames_u8(1, 224, 224, seed=5), cw, cb, fc6, fc7, VGG19_E)
     assert got.shape == want.shape == (1, 4096)
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f4: the ResNet-152 variant (get_rgb_features.py:127-131)
+# ---------------------------------------------------------------------------------------------------------------------
+def _torch_resnet(sd, blocks, width):
+    """Bottleneck ResNet up to the global average pool from torch.nn.functional ops (what torchvision's resnet152 minus its fc
+    head computes in eval mode): conv(bias=False) -> batch_norm(running stats) -> relu, max_pool2d(3, 2, 1), Bottleneck blocks
+    (stride on the 3x3 convolution, 1x1 downsample on the first block of each layer), adaptive_avg_pool2d(1)."""
+    t = {k: torch.from_numpy(v) for k, v in sd.items()}
+
+    def cbn(x, conv, bn, stride, pad):
+        x = F.conv2d(x, t[conv + ".weight"], None, stride, pad)
+        return F.batch_norm(x, t[bn + ".running_mean"], t[bn + ".running_var"], t[bn + ".weight"], t[bn + ".bias"], False, 0.0, 1e-5)
+
+    def run(x):
+        x = F.max_pool2d(F.relu(cbn(x, "conv1", "bn1", 2, 3)), 3, 2, 1)
+        for li, nb in enumerate(blocks):
+            for b in range(nb):
+                pre, s = f"layer{li + 1}.{b}", 2 if (b == 0 and li > 0) else 1
+                identity = cbn(x, pre + ".downsample.0", pre + ".downsample.1", s, 0) if b == 0 else x
+                o = F.relu(cbn(x, pre + ".conv1", pre + ".bn1", 1, 0))
+                o = F.relu(cbn(o, pre + ".conv2", pre + ".bn2", s, 1))
+                x = F.relu(cbn(o, pre + ".conv3", pre + ".bn3", 1, 0) + identity)
+        return F.adaptive_avg_pool2d(x, (1, 1)).flatten(1)
+    return run
+
+
+@pytest.mark.parametrize("hw,blocks,width", [((64, 64), (1, 2, 2, 1), 8), ((96, 80), (2, 1, 3, 2), 4), ((224, 224), (1, 1, 2, 1), 16)])
+def test_oracle_resnet_matches_torch_functional(oracle, hw, blocks, width):
+    """The oracle's folded-BatchNorm restatement == the unfolded torch composition to 1e-4 of the activation scale, on reduced
+    stacks that reach every layer form (7x7/2 stem, 3x3/2 max-pool, 1x1, 3x3 stride 1 and 2, downsample stride 1 and 2,
+    residual add, global average), odd spatial sizes included."""
+    H, W = hw
+    frames = synth.frames_u8(2, H, W, seed=7)
+    sd = synth.resnet_weights(blocks, width, seed=7)
+    got = oracle.resnet_pool(frames, sd, blocks, width)
+    with torch.no_grad():
+        want = _torch_resnet(sd, blocks, width)(torch.from_numpy(oracle.frames_normalize(frames))).numpy()
+    assert got.shape == want.shape == (2, 32 * width)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want).max())))
+
+
+def test_oracle_resnet152_full_size_matches_torch_modules(oracle, golden):
+    """f4 at FULL size: ResNet-152 (3 / 8 / 36 / 3 Bottleneck blocks, width 64 -> 2048-d), one 224x224 frame, against fixture G12
+    (the same network built from torch.nn modules by tools/gen_golden.py).  'Unpinned vs torchvision' like the VGG path
+    (absent here, weights a network fetch): this pins the architecture's composition and the arithmetic."""
+    want = golden("g12_resnet_full.npz")["pooled"][:1]
+    sd = synth.resnet_weights((3, 8, 36, 3), 64, seed=12)
+    got = oracle.resnet_pool(synth.frames_u8(2, 224, 224, seed=12)[:1], sd)
+    assert got.shape == want.shape == (1, 2048)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want).max())))

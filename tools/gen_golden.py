@@ -12,7 +12,8 @@ Fixtures:  G1 encoders, G2 scoring + both evaluate() dicts (n=6, 
 G3 generate_moments / get_iou, G4 load_video_features pooling, G5 tokeniser + WordIndexer, G6 validate_epoch,
 G7 ranking loss, G8 evaluate() with the 'chance' baseline, G9 one full-size VGG-19 frame through torch.nn modules,
 G10 encoder gradients (loss.backward() through CALModel), G11 DiDeMoDataset.__getitem__ of get_rgb_features.py (frame selection +
-normalisation) with torchvision.io.read_video stubbed by a seeded frame generator.
+normalisation) with torchvision.io.read_video stubbed by a seeded frame generator, G12 two full-size frames through a
+ResNet-152 built from torch.nn modules.
 """
 import json
 import random
@@ -444,12 +445,70 @@ def g11_frame_front_end():
     print("G11", {i: len(out[f"idx_{i}"]) for i in range(len(G11_CASES))}, out["norm_frames"].shape)
 
 
+def torch_resnet(sd, blocks, width):
+    """A Bottleneck ResNet up to its global average pool built from torch.nn modules -- the layers torchvision.models.resnet152
+    is made of (torchvision itself is absent here): Conv2d(bias=False) + BatchNorm2d + ReLU, MaxPool2d(3, 2, 1), Bottleneck
+    blocks with the stride on the 3x3 convolution and a 1x1 downsample branch on the first block of each layer,
+    AdaptiveAvgPool2d((1, 1)); get_rgb_features.py:127-131 keeps exactly children()[:-1] of that model."""
+    import torch.nn as nn
+
+    def cb(conv, bn, cin, cout, k, s, p_):
+        c = nn.Conv2d(cin, cout, k, s, p_, bias=False)
+        c.weight.data.copy_(torch.from_numpy(sd[conv + ".weight"]))
+        b = nn.BatchNorm2d(cout)
+        b.weight.data.copy_(torch.from_numpy(sd[bn + ".weight"])); b.bias.data.copy_(torch.from_numpy(sd[bn + ".bias"]))
+        b.running_mean.copy_(torch.from_numpy(sd[bn + ".running_mean"])); b.running_var.copy_(torch.from_numpy(sd[bn + ".running_var"]))
+        return c, b
+
+    class Bottleneck(nn.Module):
+        def __init__(self, pre, cin, mid, stride, down):
+            super().__init__()
+            self.conv1, self.bn1 = cb(pre + ".conv1", pre + ".bn1", cin, mid, 1, 1, 0)
+            self.conv2, self.bn2 = cb(pre + ".conv2", pre + ".bn2", mid, mid, 3, stride, 1)
+            self.conv3, self.bn3 = cb(pre + ".conv3", pre + ".bn3", mid, 4 * mid, 1, 1, 0)
+            self.relu = nn.ReLU(inplace=True)
+            self.downsample = nn.Sequential(*cb(pre + ".downsample.0", pre + ".downsample.1", cin, 4 * mid, 1, stride, 0)) if down else None
+
+        def forward(self, x):
+            identity = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.relu(self.bn2(self.conv2(out)))
+            out = self.bn3(self.conv3(out))
+            return self.relu(out + identity)
+
+    layers = [*cb("conv1", "bn1", 3, width, 7, 2, 3), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2, 1)]
+    cin = width
+    for li, nb in enumerate(blocks):
+        mid = width * 2 ** li
+        for b in range(nb):
+            layers.append(Bottleneck(f"layer{li + 1}.{b}", cin, mid, 2 if (b == 0 and li > 0) else 1, b == 0))
+            cin = 4 * mid
+    layers.append(nn.AdaptiveAvgPool2d((1, 1)))
+    return nn.Sequential(*layers).eval()
+
+
+def g12_resnet_full():
+    """f4 at FULL size: two 224x224 frames through ResNet-152 (blocks 3/8/36/3, width 64 -> 2048-d) built from torch.nn modules,
+    seeded full-width weights (synth.resnet_weights), input normalised as get_rgb_features.py:64-69 does."""
+    blocks, width = (3, 8, 36, 3), 64
+    sd = synth.resnet_weights(blocks, width, seed=12)
+    frames = synth.frames_u8(2, 224, 224, seed=12)
+    mean = torch.tensor([0.485, 0.456, 0.406]); std = torch.tensor([0.229, 0.224, 0.225])
+    x = torch.from_numpy(frames).transpose(3, 1).transpose(2, 3).float().div(255)
+    x = x.sub(mean[None, :, None, None]).div(std[None, :, None, None])
+    with torch.no_grad():
+        out = torch_resnet(sd, blocks, width)(x).flatten(1).numpy()
+    np.savez_compressed(OUT / "g12_resnet_full.npz", pooled=out.astype(np.float32))
+    print("G12", out.shape, float(out.max()), float(out.mean()))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                       # python tools/gen_golden.py g11_frame_front_end
         for name in sys.argv[1:]:
             globals()[name]()
         sys.exit(0)
     g11_frame_front_end()
+    g12_resnet_full()
     g3_moments_iou()
     g5_tokens()
     g4_pooling()

@@ -71,6 +71,8 @@ SIGNATURES = {
     "vfr_maxpool2_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vfr_adaptive_avgpool7_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vfr_vgg_fc7_workspace_bytes": (_sz, [_i32, _i32, _i32, _vp, _i32, _i32]),
+    "vfr_resnet_pool_workspace_bytes": (_sz, [_i32, _i32, _i32, _vp, _i32]),
+    "vfr_resnet_pool_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _f32, _vp, _vp, _sz, _vp]),
     "vfr_vgg_fc7_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
 }
 
@@ -504,6 +506,57 @@ def vgg_fc7(frames_thwc, cfg, conv_w, conv_b, fc6, fc7) -> torch.Tensor:
                                  ctypes.cast(wp, ctypes.c_void_p), ctypes.cast(bp, ctypes.c_void_p), f6w.data_ptr(),
                                  f6b.data_ptr(), f7w.data_ptr(), f7b.data_ptr(), fc_dim, out.data_ptr(), ws.data_ptr(),
                                  nbytes, _stream()), "vfr_vgg_fc7_f32")
+    return out
+
+
+RESNET152_BLOCKS = (3, 8, 36, 3)
+
+
+def resnet_conv_plan(blocks=RESNET152_BLOCKS, width: int = 64):
+    """The convolutions of a torchvision Bottleneck ResNet in execution order: (conv prefix, bn prefix) of the state dict --
+    the stem, then per block conv1, conv2, conv3 and, for the first block of a layer, downsample.0 / downsample.1."""
+    plan = [("conv1", "bn1")]
+    for li, nb in enumerate(blocks):
+        for b in range(nb):
+            pre = f"layer{li + 1}.{b}"
+            plan += [(f"{pre}.conv1", f"{pre}.bn1"), (f"{pre}.conv2", f"{pre}.bn2"), (f"{pre}.conv3", f"{pre}.bn3")]
+            if b == 0:
+                plan.append((f"{pre}.downsample.0", f"{pre}.downsample.1"))
+    return plan
+
+
+def resnet_pack(state_dict, blocks=RESNET152_BLOCKS, width: int = 64, device="cuda:0"):
+    """torchvision-style resnet state dict (tensors or numpy) -> (conv weights, packed BatchNorm tensors [4, C]) on the device,
+    in the order ``vfr_resnet_pool_f32`` takes them.  Done once per model; the result is passed to ``resnet_pool``."""
+    def t(x):
+        return torch.as_tensor(x, dtype=torch.float32).to(device).contiguous()
+    convs, bns = [], []
+    for conv, bn in resnet_conv_plan(blocks, width):
+        convs.append(t(state_dict[conv + ".weight"]))
+        bns.append(torch.stack([t(state_dict[bn + ".weight"]), t(state_dict[bn + ".bias"]), t(state_dict[bn + ".running_mean"]),
+                                t(state_dict[bn + ".running_var"])]).contiguous())
+    return convs, bns
+
+
+def resnet_pool(frames_thwc, packed, blocks=RESNET152_BLOCKS, width: int = 64, eps: float = 1e-5) -> torch.Tensor:
+    """uint8 [T,H,W,3] -> pooled ResNet features [T, 32 * width]  (get_rgb_features.py:64-69,127-131, 147)."""
+    fr = _dev(frames_thwc, torch.uint8, "frames")
+    T, H, W, _ = fr.shape
+    convs, bns = packed
+    convs = [_dev(w, torch.float32, "conv_w") for w in convs]
+    bns = [_dev(b, torch.float32, "bn") for b in bns]
+    nconv = 1 + sum(3 * n + 1 for n in blocks)
+    if len(convs) != nconv or len(bns) != nconv:
+        raise RuntimeError(f"resnet_pool: expected {nconv} convolutions for blocks {tuple(blocks)}, got {len(convs)}")
+    bl = (ctypes.c_int * 4)(*[int(b) for b in blocks])
+    wp = (ctypes.c_void_p * nconv)(*[w.data_ptr() for w in convs])
+    bp = (ctypes.c_void_p * nconv)(*[b.data_ptr() for b in bns])
+    out = torch.empty((T, 32 * width), dtype=torch.float32, device=fr.device)
+    nbytes = lib().vfr_resnet_pool_workspace_bytes(T, H, W, ctypes.cast(bl, ctypes.c_void_p), width)
+    ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=fr.device)
+    _check(lib().vfr_resnet_pool_f32(fr.data_ptr(), T, H, W, ctypes.cast(bl, ctypes.c_void_p), width, ctypes.cast(wp, ctypes.c_void_p),
+                                     ctypes.cast(bp, ctypes.c_void_p), eps, out.data_ptr(), ws.data_ptr(), nbytes, _stream()),
+           "vfr_resnet_pool_f32")
     return out
 
 

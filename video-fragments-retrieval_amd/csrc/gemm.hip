@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
             float v = acc[i][j];
             if (g.epi & EPI_BIAS2) v = v + (g.bias[n] + g.bias2[n]);
             else if (g.epi & EPI_BIAS) v = v + g.bias[n];
+            if (g.epi & EPI_RES) v = v + g.res[m * g.ldr + n];
             if (g.epi & EPI_RELU) v = v > 0.0f ? v : 0.0f;
             g.out[m * g.ldo + n] = v;
         }
@@ -707,6 +708,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 if (row >= g.M) continue;
                 float v = acc[ti][tj][r];
                 if (g.epi & (EPI_BIAS | EPI_BIAS2)) v = v + badd;
+                if (g.epi & EPI_RES) v = v + g.res[row * g.ldr + col];
                 if (g.epi & EPI_RELU) v = v > 0.0f ? v : 0.0f;
                 g.out[row * g.ldo + col] = v;
             }
@@ -904,6 +906,7 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
     VFR_REQUIRE(g.A && g.W && g.out && g.M > 0 && g.N > 0 && g.K >= 0, VFR_EINVAL, "gemm_nt: bad argument");
     VFR_REQUIRE(!(g.epi & (EPI_BIAS | EPI_BIAS2)) || g.bias, VFR_EINVAL, "gemm_nt: bias flag without bias");
     VFR_REQUIRE(!(g.epi & EPI_BIAS2) || g.bias2, VFR_EINVAL, "gemm_nt: bias2 flag without bias2");
+    VFR_REQUIRE(!(g.epi & EPI_RES) || g.res, VFR_EINVAL, "gemm_nt: residual flag without res");
     VFR_REQUIRE(g.lda < (1ll << 22) && g.ldw < (1ll << 22), VFR_EUNSUPPORTED, "gemm_nt: leading dimension of 4M floats or more");
     ProfScope prof(g.site, st);
     dim3 grid((unsigned)cdiv(g.M, MBM), (unsigned)cdiv(g.N, MBN));

@@ -74,12 +74,14 @@ enum : int {
     EPI_BIAS2 = 2,     // + (bias[n] + bias2[n])   (LSTM: b_ih + b_hh)
     EPI_RELU = 4,      // max(x, 0) last
     EPI_VIS = 8,       // clip-encoder hidden layer: x = ((chain + vis_cx[vis_row[m]][n]) + fma(te1, vis_w1[n], fma(te0, vis_w0[n], 0))) + bias[n]
+    EPI_RES = 16,      // + res[m][n] after the bias, before the ReLU (a residual block's identity branch)
 };
 struct GemmArgs {
     const float *A; int64_t lda;
     const float *W; int64_t ldw;
     const float *Cin; int64_t ldc;     // nullable
     const float *bias, *bias2;         // nullable
+    const float *res; int64_t ldr;     // EPI_RES
     float *out; int64_t ldo;
     int64_t M; int N; int K;
     int epi;

@@ -11,8 +11,10 @@
   video, unreadable videos appended to the missed list.
 
 Decoding mp4 (``torchvision.io.read_video``, ``:40-44``) is codec I/O and stays the caller's: ``decoder(video, num_segments)``
-returns ``(uint8 frames [T, H, W, 3], fps)`` -- or ``(None, 0)`` for an unreadable file.  The ResNet152 variant (``:127-131``)
-needs fetched weights and is not built.
+returns ``(uint8 frames [T, H, W, 3], fps)`` -- or ``(None, 0)`` for an unreadable file.  Both extractor variants of the
+reference are built: ``model_type="vgg19"`` (fc7, 4096-d, ``:122-126``; ``weights`` = (conv_w, conv_b, fc6, fc7)) and
+``model_type="resnet152"`` (global average pool, 2048-d, ``:127-131``; ``weights`` = ``_vfr.resnet_pack(state_dict)``).  The
+pretrained weights themselves are a network fetch and the caller's to provide.
 """
 from __future__ import annotations
 
@@ -48,22 +50,31 @@ def sample_frames(num_frames: int, fps: float, num_segments: int) -> np.ndarray:
     return np.concatenate([[0], np.rint(cur[keep]).astype(np.int64)])
 
 
-def extract_video(frames_u8, fps: float, num_segments: int, weights, cfg=None) -> torch.Tensor:
-    """uint8 frames [T, H, W, 3] (device tensor or numpy) -> fc7 features [T_sel, fc_dim] on the device."""
+def extract_video(frames_u8, fps: float, num_segments: int, weights, cfg=None, model_type: str = "vgg19") -> torch.Tensor:
+    """uint8 frames [T, H, W, 3] (device tensor or numpy) -> features [T_sel, FEATURE_DIM[model_type]] on the device.
+    ``cfg``: the VGG layer list, or ``(blocks, width)`` of the ResNet (defaults: VGG-19 "E" / ResNet-152)."""
     from . import _vfr
-    conv_w, conv_b, fc6, fc7 = weights
-    dev = conv_w[0].device
+    if model_type == "resnet152":
+        dev = weights[0][0].device
+    elif model_type == "vgg19":
+        dev = weights[0][0].device
+    else:
+        raise ValueError(f"unknown extractor {model_type!r} (get_rgb_features.py:122-131 has vgg19 and resnet152)")
     fr = torch.as_tensor(frames_u8).to(dev)
     idx = torch.from_numpy(sample_frames(int(fr.shape[0]), fps, num_segments)).to(dev)
     sel = fr.index_select(0, idx).contiguous()                                # (:59) -- a gather, then everything in HIP
+    if model_type == "resnet152":
+        blocks, width = cfg if cfg is not None else (_vfr.RESNET152_BLOCKS, 64)
+        return _vfr.resnet_pool(sel, weights, blocks, width)
+    conv_w, conv_b, fc6, fc7 = weights
     return _vfr.vgg_fc7(sel, VGG19_CFG if cfg is None else cfg, conv_w, conv_b, fc6, fc7)
 
 
 def extract_dataset(dataset_info, decoder, features_dir, weights, model_type: str = "vgg19", cfg=None,
                     missed_path="missed_videos_features.json"):
     """The extraction loop with the reference's resume / skip-and-record behaviour.  Returns (written, missed) video lists."""
-    if model_type != "vgg19":
-        raise NotImplementedError("only the vgg19 variant is built (resnet152 needs fetched weights: SURVEY 8f row 4)")
+    if model_type not in ("vgg19", "resnet152"):
+        raise ValueError(f"unknown extractor {model_type!r} (get_rgb_features.py:122-131 has vgg19 and resnet152)")
     ft = Path(features_dir)
     ft.mkdir(exist_ok=True)
     prefix = f"{model_type}_ft_"
@@ -80,7 +91,7 @@ def extract_dataset(dataset_info, decoder, features_dir, weights, model_type: st
         if frames is None or len(frames) == 0:                                                # (:75-78,152-153)
             missed.append(video)
             continue
-        feats = extract_video(frames, fps, nseg, weights, cfg)
+        feats = extract_video(frames, fps, nseg, weights, cfg, model_type)
         np.save(ft / f"{prefix}{video}", feats.cpu().numpy())                                # (:150-151)
         written.append(video)
     missed_path.write_text(json.dumps(missed))                                               # (:155-156)
