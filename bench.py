@@ -54,6 +54,7 @@ def parse():
                     help="vfr_set_option passthrough for parameter sweeps (results must not change: compare the checksums)")
     ap.add_argument("--host-feed", action="store_true",
                     help="also time the pass with the pooled features in pinned HOST memory (PCIe-inclusive; extra field, never `value`)")
+    ap.add_argument("--vgg-videos", type=int, default=24, help="videos of the extractor-loop sub-record (BASELINE config 3's loop)")
     ap.add_argument("--plant-alpha", type=float, default=0.5, help="noise scale of the planted-query sub-record (realistic_gt)")
     ap.add_argument("--cpu-queries", type=int, default=1024, help="queries of the batch the CPU oracle leg runs (against ALL videos)")
     ap.add_argument("--parity-ranks", type=int, default=64, help="queries whose ground-truth rank counts the oracle recomputes")
@@ -524,6 +525,32 @@ def extras(args, dev, model, seg, ctx, clip_off, tokens, make_shard, ranks_of, o
                      "ms_per_video": dt_v * 1e3, "frames_per_s": 150 / dt_v, "videos_per_s": 1 / dt_v,
                      "tflops": gflop / dt_v / 1e3, "frac_fp32_mfma_peak": gflop / dt_v / 1e3 / FP32_PEAK_TFLOPS,
                      "finite": bool(torch.isfinite(feat).all())}
+        # the LOOP of get_rgb_features.py:134-153 (BASELINE config 3 is "1k videos", not one): features.extract_dataset over
+        # `--vgg-videos` synthetic videos of 900 decoded frames at 30 fps (-> 150 selected), decoder = a seeded frame store in host
+        # memory (decode speed is the codec's, not ours), one .npy per video written to a scratch directory
+        import tempfile
+        from vfr_amd import features
+        nvid = args.vgg_videos
+        host_videos = [frames.cpu().numpy()[torch.randperm(150, generator=torch.Generator().manual_seed(i)).numpy()][np.repeat(np.arange(150), 6)]
+                       for i in range(2)]                                   # two distinct 900-frame clips, reused round-robin
+        info = [dict(video=f"v{i:04d}", num_segments=6) for i in range(nvid)]
+        decoder = lambda video, nseg: (host_videos[int(video[1:]) % 2], 30.0)
+        weights = (cw, cb, fc6, fc7)
+        loop = {}
+        for tag, pipe in (("pipelined", True), ("serial", False)):
+            with tempfile.TemporaryDirectory() as td:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                written, _ = features.extract_dataset(info, decoder, Path(td) / "features_vgg19", weights, missed_path=Path(td) / "missed.json",
+                                                      pipeline=pipe)
+                torch.cuda.synchronize()
+                dt_l = time.perf_counter() - t0
+                nfr = sum(np.load(Path(td) / "features_vgg19" / f"vgg19_ft_{v}.npy", mmap_mode="r").shape[0] for v in written)
+            loop[tag] = {"videos": len(written), "frames": int(nfr), "s": dt_l, "frames_per_s": nfr / dt_l, "videos_per_s": len(written) / dt_l}
+        ex["vgg"]["loop"] = {"what": f"features.extract_dataset over {nvid} videos x 900 decoded frames (150 kept): decode stub -> pinned H2D -> frame "
+                                     "selection + VGG19-fc7 -> D2H -> np.save per video; pipelined = reader / device / writer overlapped",
+                             **loop, "loop_frames_per_s": loop["pipelined"]["frames_per_s"],
+                             "frac_of_kernel_only_rate": loop["pipelined"]["frames_per_s"] / (150 / dt_v)}
     except RuntimeError as e:                                   # e.g. out of memory on a shared device: report, do not hide
         ex["vgg"] = {"error": str(e)[:200]}
     ex["cpu_baseline_loop"] = cpu_loop_baseline(emb, clip_off, Q, counts_all)

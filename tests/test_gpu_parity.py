@@ -1073,6 +1073,23 @@ def test_extractor_front_end_to_pooled_dataset(vfr, oracle, tmp_path):
         want = oracle.vgg_fc7(frames[mask], cw, cb, fc6, fc7, cfg)
         assert got.shape == want.shape and np.array_equal(got, want), name
     assert np.load(ft / "vgg19_ft_b.npy").shape[0] == 138
+    # the serial loop (pipeline=False) writes the same files and lists
+    ft2 = tmp_path / "features_serial"
+    written2, missed2 = features.extract_dataset(info, decoder, ft2, weights, cfg=cfg, missed_path=tmp_path / "missed2.json", pipeline=False)
+    assert (written2, missed2) == (written, missed)
+    for name in clips:
+        assert np.array_equal(np.load(ft2 / f"vgg19_ft_{name}.npy"), np.load(ft / f"vgg19_ft_{name}.npy"))
+    # a decoder that fails mid-way surfaces its exception and leaves no thread behind
+    import threading
+    before = threading.active_count()
+
+    def bad_decoder(video, nseg):
+        if video == "b":
+            raise OSError("cannot open b.mp4")
+        return clips[video][:2]
+    with pytest.raises(OSError, match="b.mp4"):
+        features.extract_dataset(info[:3], bad_decoder, tmp_path / "features_bad", weights, cfg=cfg, missed_path=tmp_path / "missed3.json")
+    assert threading.active_count() == before
 
 
 @pytest.mark.gpu

@@ -50,6 +50,22 @@ def sample_frames(num_frames: int, fps: float, num_segments: int) -> np.ndarray:
     return np.concatenate([[0], np.rint(cur[keep]).astype(np.int64)])
 
 
+def select_frames(frames_u8, fps: float, num_segments: int, pin: bool = False) -> torch.Tensor:
+    """The kept frames of a decoded clip (``:45-59``), selected WHERE THE FRAMES ARE: a host array is gathered on the host (one
+    frame in six of a 30 fps clip survives: the H2D copy carries 23 MB instead of 135), a device tensor on the device.
+    ``pin``: gather into page-locked memory (for an asynchronous copy).  A clip whose frame count is already the selection's
+    (``fps`` <= 0: pre-selected) passes through."""
+    fr = torch.as_tensor(frames_u8)
+    if fps is not None and fps > 0:
+        idx = torch.from_numpy(sample_frames(int(fr.shape[0]), fps, num_segments))
+        if fr.device.type == "cpu":
+            out = torch.empty((len(idx),) + tuple(fr.shape[1:]), dtype=fr.dtype, pin_memory=pin)
+            torch.index_select(fr, 0, idx, out=out)
+            return out
+        return fr.index_select(0, idx.to(fr.device)).contiguous()
+    return fr.contiguous()
+
+
 def extract_video(frames_u8, fps: float, num_segments: int, weights, cfg=None, model_type: str = "vgg19") -> torch.Tensor:
     """uint8 frames [T, H, W, 3] (device tensor or numpy) -> features [T_sel, FEATURE_DIM[model_type]] on the device.
     ``cfg``: the VGG layer list, or ``(blocks, width)`` of the ResNet (defaults: VGG-19 "E" / ResNet-152)."""
@@ -60,9 +76,7 @@ def extract_video(frames_u8, fps: float, num_segments: int, weights, cfg=None, m
         dev = weights[0][0].device
     else:
         raise ValueError(f"unknown extractor {model_type!r} (get_rgb_features.py:122-131 has vgg19 and resnet152)")
-    fr = torch.as_tensor(frames_u8).to(dev)
-    idx = torch.from_numpy(sample_frames(int(fr.shape[0]), fps, num_segments)).to(dev)
-    sel = fr.index_select(0, idx).contiguous()                                # (:59) -- a gather, then everything in HIP
+    sel = select_frames(frames_u8, fps, num_segments).to(dev)                 # (:59) -- a gather, then everything in HIP
     if model_type == "resnet152":
         blocks, width = cfg if cfg is not None else (_vfr.RESNET152_BLOCKS, 64)
         return _vfr.resnet_pool(sel, weights, blocks, width)
@@ -71,8 +85,14 @@ def extract_video(frames_u8, fps: float, num_segments: int, weights, cfg=None, m
 
 
 def extract_dataset(dataset_info, decoder, features_dir, weights, model_type: str = "vgg19", cfg=None,
-                    missed_path="missed_videos_features.json"):
-    """The extraction loop with the reference's resume / skip-and-record behaviour.  Returns (written, missed) video lists."""
+                    missed_path="missed_videos_features.json", pipeline: bool = True):
+    """The extraction loop with the reference's resume / skip-and-record behaviour.  Returns (written, missed) video lists.
+
+    ``pipeline=True`` (ROCm device only): the loop of ``get_rgb_features.py:134-153`` as a three-stage pipeline -- a reader thread
+    decodes video i + 1 into page-locked memory while the device runs the stack on video i (frames H2D, index-select,
+    normalise, the whole network: all queued asynchronously on the compute stream), and a writer thread waits for video
+    i - 1's D2H copy (into a page-locked slot, behind an event) and ``np.save``s it.  The device never waits for the decoder, the
+    copy back or the file system; files and lists are those of the serial loop."""
     if model_type not in ("vgg19", "resnet152"):
         raise ValueError(f"unknown extractor {model_type!r} (get_rgb_features.py:122-131 has vgg19 and resnet152)")
     ft = Path(features_dir)
@@ -82,17 +102,97 @@ def extract_dataset(dataset_info, decoder, features_dir, weights, model_type: st
     missed_path = Path(missed_path)
     missed = json.loads(missed_path.read_text()) if missed_path.exists() else []            # (:107-111)
     skip = set(done) | set(missed)
+    todo = [item for item in dataset_info if item["video"] not in skip]                       # (:115-116)
+    dev = _weights_device(weights, model_type)
     written = []
-    for item in dataset_info:                                                                 # (:115-116)
-        video, nseg = item["video"], item["num_segments"]
-        if video in skip:
-            continue
-        frames, fps = decoder(video, nseg)
-        if frames is None or len(frames) == 0:                                                # (:75-78,152-153)
-            missed.append(video)
-            continue
-        feats = extract_video(frames, fps, nseg, weights, cfg, model_type)
-        np.save(ft / f"{prefix}{video}", feats.cpu().numpy())                                # (:150-151)
-        written.append(video)
+    if not (pipeline and dev is not None and dev.type == "cuda"):
+        for item in todo:
+            video, nseg = item["video"], item["num_segments"]
+            frames, fps = decoder(video, nseg)
+            if frames is None or len(frames) == 0:                                            # (:75-78,152-153)
+                missed.append(video)
+                continue
+            feats = extract_video(frames, fps, nseg, weights, cfg, model_type)
+            np.save(ft / f"{prefix}{video}", feats.cpu().numpy())                            # (:150-151)
+            written.append(video)
+        missed_path.write_text(json.dumps(missed))                                           # (:155-156)
+        return written, missed
+
+    import queue
+    import threading
+    decoded = queue.Queue(maxsize=2)            # reader -> main: (video, nseg, pinned uint8 frames | None, fps)
+    to_write = queue.Queue(maxsize=3)           # main -> writer: (video, event, pinned float32 features)
+    errors = []
+
+    stop = threading.Event()
+
+    def reader():
+        try:
+            for item in todo:
+                if stop.is_set():
+                    break
+                video, nseg = item["video"], item["num_segments"]
+                frames, fps = decoder(video, nseg)
+                if frames is None or len(frames) == 0:
+                    decoded.put((video, nseg, None, 0.0))
+                    continue
+                decoded.put((video, nseg, select_frames(frames, fps, nseg, pin=True), 0.0))    # kept frames only, page-locked
+        except BaseException as e:              # noqa: BLE001 -- handed to the main thread
+            errors.append(e)
+        finally:
+            decoded.put(None)
+
+    def writer():
+        try:
+            while True:
+                job = to_write.get()
+                if job is None:
+                    return
+                video, event, host = job
+                event.synchronize()
+                np.save(ft / f"{prefix}{video}", host.numpy())                               # (:150-151)
+        except BaseException as e:              # noqa: BLE001
+            errors.append(e)
+            while to_write.get() is not None:   # keep draining so the main thread never blocks on a full queue
+                pass
+
+    threads = [threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)]
+    for t in threads:
+        t.start()
+    try:
+        while True:
+            job = decoded.get()
+            if job is None:
+                break
+            video, nseg, frames, fps = job
+            if frames is None:                                                                # (:75-78,152-153)
+                missed.append(video)
+                continue
+            feats = extract_video(frames.to(dev, non_blocking=True), fps, nseg, weights, cfg, model_type)
+            host = torch.empty(feats.shape, dtype=feats.dtype, pin_memory=True)
+            host.copy_(feats, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+            to_write.put((video, event, host))
+            written.append(video)
+    finally:
+        stop.set()
+        while threads[0].is_alive():            # an exception above: let the reader finish its put, then stop
+            try:
+                decoded.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        to_write.put(None)
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
     missed_path.write_text(json.dumps(missed))                                               # (:155-156)
     return written, missed
+
+
+def _weights_device(weights, model_type):
+    try:
+        return weights[0][0].device
+    except (TypeError, IndexError, AttributeError):
+        return None
