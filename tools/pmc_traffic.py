@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 SITE_OF = (("lstm_step_mfma_pair", "gemm_lstm_rec"), ("score_mfma_kernel<21, 8, 2", "score_fused"), ("score_mfma_kernel<6", "score_fused"),
-           ("score_pairs_exact_kernel", "score_pairs"), ("segment_pool_norm", "pool"), ("topk_merge", "topk_merge"),
+           ("score_pairs_video_kernel", "score_pairs"), ("score_pairs_exact_kernel", "score_pairs"), ("segment_pool_norm", "pool"), ("topk_merge", "topk_merge"),
            ("gemm_nt_mfma<true, 2>", "gemm_vis_seg"))
 
 
