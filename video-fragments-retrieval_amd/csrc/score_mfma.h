@@ -637,8 +637,13 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
 // from per-lane LDS reads: ~4.5 pairs shared a video, 75 % of the lanes worked and the kernel waited on LDS -- 2.2 ms for the
 // 7 % of pairs of the bench corpus.)
 // ---------------------------------------------------------------------------------------------------------------------
+// One or two query groups (Nq <= 128): a video has a handful of marked pairs, a wave per video would run its 7 us of chains for 5
+// of 64 lanes (10 000 such waves cost 0.18 ms at 64 queries).  The VB = 8 instantiation gives a wave EIGHT consecutive videos: their
+// rows are staged together (they are adjacent in V), lane = (video, group) slot expands the bitmaps (the slots of consecutive
+// videos are adjacent in memory: one coalesced load), and a batch mixes pairs of all eight videos -- every lane reads ITS
+// video's row from LDS (the rows of different videos sit 8400 bytes apart: distinct banks for up to 16 videos).
 constexpr int PV_LIST = 1024;                // list window: entries expanded at a time (a 64-group chunk rarely marks more)
-template <int NT, int NR>
+template <int NT, int NR, int VB>
 __global__ __launch_bounds__(64) void score_pairs_video_kernel(const float *__restrict__ Qp, const float *__restrict__ Vp,
                                                                const int32_t *__restrict__ clip_off,
                                                                const int64_t *__restrict__ mom_off,
@@ -646,24 +651,28 @@ __global__ __launch_bounds__(64) void score_pairs_video_kernel(const float *__re
                                                                const int64_t *__restrict__ rank_idx, ScoreArgs a, MfmaArgs m)
 {
     static_assert(NR == 2, "two rank keys per query (the bitmap holds one mask per key)");
-    constexpr int ROW4 = FAST_D / 4, NLD = (NT * ROW4 + 63) / 64;
-    // 16 KB of LDS and ~160 VGPRs: ten waves per CU -- the kernel is a chain of dependent gathers (bitmap -> query rows ->
+    constexpr int ROW4 = FAST_D / 4;
+    // VB = 1: 16 KB of LDS and ~135 VGPRs: ten waves per CU -- the kernel is a chain of dependent gathers (bitmap -> query rows ->
     // bound table) around 7 us of arithmetic per batch, and lives on the waves it has in flight
-    __shared__ __attribute__((aligned(16))) float vst[NT * FAST_D];     // clip rows of this video
-    __shared__ unsigned short list[PV_LIST];                             // (group in chunk) << 8 | lane bit << 2 | key mask
-    __shared__ float dx[64 * (NT + 1)];                                  // tie walk only: exact distances [pair][clip]
-    const int lane = threadIdx.x, v = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) float vst[(VB * NT + (VB > 1 ? 3 : 0)) * FAST_D];   // clip rows of this wave's video(s)
+    __shared__ unsigned short list[PV_LIST];                             // slot << 8 | lane bit << 2 | key mask
+    __shared__ float dx[64 * (NT + 1)];                                  // exact distances [pair][clip] (partial sums first)
+    const int lane = threadIdx.x, v = blockIdx.x * VB;                   // first video of this wave
     const int groups = a.num_groups;
-    const int c0 = clip_off[v], n = clip_off[v + 1] - c0;
+    const int nvid = VB > 1 ? (a.Nv - v < VB ? a.Nv - v : VB) : 1;
+    const int c0 = clip_off[v], rows_total = clip_off[v + nvid] - c0;
+    const int n = VB > 1 ? a.ds_rows : rows_total;                       // VB > 1: the bank's largest clip count bounds the chain loop
     const int64_t mbase = mom_off[v];
     bool staged = false;
     const float2v e2 = {a.eps, a.eps};
     unsigned long long npairs = 0;
-    for (int gb = 0; gb < groups; gb += 64) {
-        // ---- the bitmaps of groups gb .. gb + 63 (lane = group) ----
-        const int g = gb + lane;
+    for (int gb = 0; gb < (VB > 1 ? 1 : groups); gb += 64) {
+        // ---- the bitmaps: lane = group gb + lane of the video (VB = 1), or slot (video, group) of the wave's videos (VB > 1:
+        // the host guarantees VB * groups <= 64) ----
+        const int g = VB > 1 ? lane % groups : gb + lane;
+        const bool slot_ok = VB > 1 ? lane < nvid * groups : g < groups;
         ulonglong2 mm = ulonglong2{0ull, 0ull};
-        if (g < groups && !m.fallback[g]) mm = m.amb[(size_t)v * groups + g];
+        if (slot_ok && !m.fallback[g]) mm = m.amb[(size_t)v * groups + (VB > 1 ? lane : g)];
         const unsigned long long any = mm.x | mm.y;
         const int c = __builtin_popcountll(any);
         int incl = c;
@@ -672,19 +681,18 @@ __global__ __launch_bounds__(64) void score_pairs_video_kernel(const float *__re
         const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total == 0) continue;
         npairs += (unsigned long long)total;
-        if (!staged) {                                                   // a video nobody marked costs one bitmap read
+        if (!staged) {                                                   // videos nobody marked cost one bitmap read
             const float4 *V4 = reinterpret_cast<const float4 *>(Vp);
             const int64_t v4_end = (int64_t)a.total_clips * ROW4;
-#pragma unroll
-            for (int t = 0; t < NLD; ++t) {
-                const int idx = lane + 64 * t;
+            const int n4 = (VB > 1 ? rows_total : NT) * ROW4;            // (VB = 1 stages NT rows: the chain loop may touch the pad rows)
+            for (int idx = lane; idx < n4; idx += 64) {
                 const int64_t g4 = (int64_t)c0 * ROW4 + idx;
-                if (idx < NT * ROW4) reinterpret_cast<float4 *>(vst)[idx] = g4 < v4_end ? V4[g4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                reinterpret_cast<float4 *>(vst)[idx] = g4 < v4_end ? V4[g4] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             staged = true;
         }
         for (int win = 0; win < total; win += PV_LIST) {
-            // ---- expand: every lane writes the set bits of its group that fall into the window ----
+            // ---- expand: every lane writes the set bits of its slot that fall into the window ----
             __builtin_amdgcn_s_waitcnt(0xC07F);                          // the previous window's list reads are done
             __builtin_amdgcn_wave_barrier();
             {
@@ -705,8 +713,14 @@ __global__ __launch_bounds__(64) void score_pairs_video_kernel(const float *__re
                 const bool have = base + lane < wtotal;
                 const unsigned ent = list[have ? base + lane : base];
                 const unsigned rmask = have ? (ent & 3u) : 0u;
-                int64_t qi = (int64_t)(gb + (int)(ent >> 8)) * 64 + ((ent >> 2) & 63u);
+                const int slot = (int)(ent >> 8);
+                const int vl = VB > 1 ? slot / groups : 0;                // this lane's video within the wave's range
+                int64_t qi = (int64_t)(VB > 1 ? slot - vl * groups : gb + slot) * 64 + ((ent >> 2) & 63u);
                 qi = qi < a.Nq ? qi : a.Nq - 1;
+                // per-lane video geometry (VB = 1: the wave's one video)
+                const int row0 = VB > 1 ? clip_off[v + vl] - c0 : 0;      // first LDS row of the lane's video
+                const int n_l = VB > 1 ? clip_off[v + vl + 1] - clip_off[v + vl] : n;
+                const int64_t mbase_l = VB > 1 ? mom_off[v + vl] : mbase;
                 // ---- the canonical chains (clip rows broadcast from LDS), the query row in two parts of 13 and 12 float4: every
                 // chain still runs k-ascending -- its accumulator waits in LDS between the parts -- and the row costs 52 registers
                 // instead of 100.  Three clips at a time (a run-time loop: the code stays small), software-pipelined over k like
@@ -730,7 +744,7 @@ __global__ __launch_bounds__(64) void score_pairs_video_kernel(const float *__re
                     }
 #pragma nounroll
                     for (int g3 = 0; g3 < ng; ++g3) {
-                        const float4 *vt = reinterpret_cast<const float4 *>(vst) + g3 * NC * ROW4;
+                        const float4 *vt = reinterpret_cast<const float4 *>(vst) + (row0 + g3 * NC) * ROW4;   // (VB = 1: wave-uniform, a broadcast)
                         float ac[NC];
 #pragma unroll
                         for (int i = 0; i < NC; ++i) ac[i] = FIRST ? 0.0f : dl[g3 * NC + i];
@@ -774,7 +788,7 @@ __global__ __launch_bounds__(64) void score_pairs_video_kernel(const float *__re
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 float d[NT];
 #pragma unroll
-                for (int cc = 0; cc < NT; ++cc) d[cc] = cc < n ? dl[cc] : __builtin_inff();
+                for (int cc = 0; cc < NT; ++cc) d[cc] = cc < n_l ? dl[cc] : __builtin_inff();
                 // ---- exact triangle: bits(sum) against the table's exclusive bounds (score < x <=> bits < LOX) ----
                 // (the 42 bound pairs are requested here, after the query row's 100 registers are dead: hoisted above the chains
                 // they would not fit)
@@ -831,14 +845,14 @@ __global__ __launch_bounds__(64) void score_pairs_video_kernel(const float *__re
 #pragma unroll
                         for (int r = 0; r < NR; ++r) { xk[r] = rank_dist[r * a.Nq + qi]; ik[r] = (unsigned)rank_idx[r * a.Nq + qi]; }
 #pragma nounroll
-                        for (int s2 = 0; s2 < n; ++s2) {
+                        for (int s2 = 0; s2 < n_l; ++s2) {
                             float sum = 0.0f;
 #pragma nounroll
-                            for (int e = s2; e < n; ++e) {
+                            for (int e = s2; e < n_l; ++e) {
                                 const float de = dx[lane * (NT + 1) + e];
                                 sum = e == s2 ? de : sum + de;
                                 const float sc = sum / (float)(e - s2 + 1);
-                                const unsigned id = (unsigned)(a.id_base + mbase + moment_index(n, s2, e));
+                                const unsigned id = (unsigned)(a.id_base + mbase_l + moment_index(n_l, s2, e));
 #pragma unroll
                                 for (int r = 0; r < NR; ++r)
                                     if (sc == xk[r] && id < ik[r]) cntr[r] += 1;
