@@ -10,6 +10,8 @@
 //   out  [B, D]     = [h_fwd | h_bwd] x Wfc^T + bfc
 //
 // 352.4 MFLOP per query; the recurrent GEMM [B,H]x[H,4H] is the MFMA-bound part.
+#include <type_traits>
+
 #include "vfr_common.h"
 #include "vfr_math.h"
 
@@ -259,6 +261,134 @@ __global__ __launch_bounds__(64) void lstm_step_small_kernel(SmallLstm a)
 constexpr int VOCAB_TABLE_MAX = 32768;
 static bool use_vocab_table(int64_t B, int T, int vocab) { return vocab <= VOCAB_TABLE_MAX && (int64_t)vocab <= 4 * B * T; }
 
+// The same step with the weight stream spread over four waves (one query, the model's shape).  The single-wave kernel above is
+// bound by what ONE wave per CU can keep in flight: 32 chunks x 1 KB x 126 waves = 4 MB chip-wide against ~0.6 us of latency
+// = 13 us for the 35 MB of weights a step reads.  Here waves 1-3 of a 256-thread workgroup only LOAD: chunk c of phase p goes to
+// loader c mod 3, which keeps two phases of 16 chunks in registers (in flight) and hands a finished phase to wave 0 through a
+// double-buffered 2 x 48 KB LDS ring; wave 0 runs the chain exactly as above (same order, same bits).  One __syncthreads per
+// phase of 48 chunks, no polling: every wave reaches every barrier.  NCH (chunks of the chain) is a template constant so the
+// phase loop is straight-line code (a loop head would drain the loads in flight).
+#ifndef VFR_S4_NL
+#define VFR_S4_NL 3
+#define VFR_S4_PER 16
+#define VFR_S4_AHEAD 2
+#endif
+constexpr int S4_NL = VFR_S4_NL, S4_PER = VFR_S4_PER, S4_AHEAD = VFR_S4_AHEAD;   // loader waves; chunks per loader and phase; phases in flight
+constexpr int S4_PH = S4_NL * S4_PER;                                              // chunks per phase
+template <int RB, int NCH>
+__global__ __launch_bounds__(64 * (S4_NL + 1), 1) void lstm_step_small4_kernel(SmallLstm a)
+{
+    constexpr int NPH = (NCH + S4_PH - 1) / S4_PH, XF = 4;
+    __shared__ float pre[RB][4][16];
+    __shared__ __attribute__((aligned(16))) float4 ring[2][S4_PH][64];
+    extern __shared__ __attribute__((aligned(16))) float xh[];          // [RB][E + H]: the rows' chain inputs
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gate = lane >> 4, ul = lane & 15, d = blockIdx.y;
+    const int unit = blockIdx.x * 16 + ul, H = a.H, E = a.E, G = 4 * H;
+    const int uc = unit < H ? unit : H - 1;
+    const int t = d ? a.T - 1 - a.step : a.step;
+    const float4 *wt = reinterpret_cast<const float4 *>(a.WT[d]) + (size_t)gate * H + uc;
+    // ---- stage [x_t | h] of the rows (all waves) ----
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int rr = r < a.B ? r : 0;
+        const float *xr = a.X + ((size_t)rr * a.T + t) * E;
+        const float *hr = a.hin + (size_t)rr * 2 * H + (size_t)d * H - E;
+        for (int c = tid; c < NCH; c += 64 * (S4_NL + 1))
+            *reinterpret_cast<float4 *>(xh + r * (E + H) + 4 * c) = *reinterpret_cast<const float4 *>((4 * c < E ? xr : hr) + 4 * c);
+    }
+    float acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.0f;
+    if (wv > 0) {
+        // ---- loaders: chunk c = S4_PH p + S4_NL j + (wv - 1), S4_AHEAD phases in flight (one register buffer per phase in flight) ----
+        const int l = wv - 1;
+        float4 bufs[S4_AHEAD][S4_PER];
+        // (a running pointer, opaque to the compiler: with constant chunk indices it precomputes every address into a register
+        // pair; chunks past the end re-read the last one: a redundant load, no branch)
+        const float4 *wp = wt + (size_t)l * G;
+        const float4 *const wlast = wt + (size_t)(NCH - 1) * G;
+        auto next = [&]() -> float4 {
+            asm volatile("" : "+v"(wp));
+            const float4 v = *(wp < wlast ? wp : wlast);
+            wp += S4_NL * (size_t)G;
+            return v;
+        };
+        auto issue = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+#pragma unroll
+            for (int j = 0; j < S4_PER; ++j) bufs[k][j] = next();
+        };
+        auto hand = [&](auto kc, auto hc) {
+            constexpr int k = decltype(kc)::value, h = decltype(hc)::value;
+#pragma unroll
+            for (int j = 0; j < S4_PER; ++j) ring[h][S4_NL * j + l][lane] = bufs[k][j];
+        };
+        auto for_phase = [&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            hand(std::integral_constant<int, p % S4_AHEAD>{}, std::integral_constant<int, p & 1>{});
+            if constexpr (p + S4_AHEAD < NPH) issue(std::integral_constant<int, p % S4_AHEAD>{});
+            __syncthreads();                                             // phase p is in the ring (p = 0: the staged rows as well)
+        };
+        issue(std::integral_constant<int, 0>{});
+        if constexpr (NPH > 1 && S4_AHEAD > 1) issue(std::integral_constant<int, 1>{});
+        if constexpr (NPH > 2 && S4_AHEAD > 2) issue(std::integral_constant<int, 2>{});
+        static_assert(NPH <= 12 && S4_AHEAD <= 3, "phase loop written out for up to 12 phases");
+#define S4_P(N) if constexpr (N < NPH) for_phase(std::integral_constant<int, N>{});
+        S4_P(0) S4_P(1) S4_P(2) S4_P(3) S4_P(4) S4_P(5) S4_P(6) S4_P(7) S4_P(8) S4_P(9) S4_P(10) S4_P(11)
+#undef S4_P
+        __syncthreads();                                                 // (matches the compute wave's barrier before the cells)
+    } else {
+        // ---- wave 0: the chain ----
+        float4 xq[XF][RB];
+        auto xfetch = [&](int slot, int c) {
+            const int cc = c < NCH ? c : NCH - 1;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) xq[slot][r] = *reinterpret_cast<const float4 *>(xh + r * (E + H) + 4 * cc);   // LDS broadcast
+        };
+#pragma unroll
+        for (int p = 0; p < NPH; ++p) {
+            __syncthreads();
+            if (p == 0) {
+#pragma unroll
+                for (int j = 0; j < XF; ++j) xfetch(j, j);
+            }
+#pragma unroll
+            for (int i = 0; i < S4_PH; ++i) {
+                const int c = S4_PH * p + i;
+                if (c < NCH) {
+                    const float4 w = ring[p & 1][i][lane];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        const float4 x = xq[c % XF][r];
+                        acc[r] = __builtin_fmaf(x.x, w.x, acc[r]); acc[r] = __builtin_fmaf(x.y, w.y, acc[r]);
+                        acc[r] = __builtin_fmaf(x.z, w.z, acc[r]); acc[r] = __builtin_fmaf(x.w, w.w, acc[r]);
+                    }
+                    xfetch(c % XF, c + XF);
+                    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // (eight ring reads in flight, not forty-eight)
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) pre[r][gate][ul] = acc[r];
+        __syncthreads();
+        // cells: lane (row r = lane >> 4, unit ul); RB <= 4 rows fit one wave
+        const int r = lane >> 4;
+        if (r < RB && r < a.B && unit < H) {
+            const float *bi = a.bih[d], *bh = a.bhh[d];
+            const float ig = c_sigmoidf(pre[r][0][ul] + (bi[unit] + bh[unit]));
+            const float fg = c_sigmoidf(pre[r][1][ul] + (bi[H + unit] + bh[H + unit]));
+            const float gg = c_tanhf(pre[r][2][ul] + (bi[2 * H + unit] + bh[2 * H + unit]));
+            const float og = c_sigmoidf(pre[r][3][ul] + (bi[3 * H + unit] + bh[3 * H + unit]));
+            const size_t ci = ((size_t)d * a.B + r) * H + unit;
+            const float cn = __builtin_fmaf(fg, a.cin[ci], ig * gg);
+            a.cout[ci] = cn;
+            a.hout[(size_t)r * 2 * H + (size_t)d * H + unit] = og * c_tanhf(cn);
+        }
+    }
+}
+
 struct LstmWs {
     float *X, *gates, *c, *c2, *hcat, *hcat2, *hfinal, *xv, *wperm, *ptab, *wt;
     int *tokidx;
@@ -356,6 +486,13 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
                              (int)B, T, E, H, step, (step == 0 && vfr::opt_lstm_skip0()) ? 0 : 1};
             vfr::ProfScope prof(vfr::SITE_GEMM_LSTM_REC, st);
             const dim3 grid((unsigned)vfr::cdiv(H, 16), 2);
+            const int nch = (a.recurrent ? E + H : E) / 4;
+            if (B == 1 && nch == 275 && vfr::opt_lstm_small4()) {       // the model's shape: four-wave weight stream
+                hipLaunchKernelGGL((vfr::lstm_step_small4_kernel<1, 275>), grid, dim3(64 * (vfr::S4_NL + 1)), (size_t)(E + H) * 4, st, a);
+                float *tmp4 = hin; hin = hout; hout = tmp4;
+                tmp4 = cin; cin = cout; cout = tmp4;
+                continue;
+            }
             switch ((int)B) {
             case 1: hipLaunchKernelGGL(vfr::lstm_step_small_kernel<1>, grid, dim3(64), (size_t)1 * (E + H) * 4, st, a); break;
             case 2: hipLaunchKernelGGL(vfr::lstm_step_small_kernel<2>, grid, dim3(64), (size_t)2 * (E + H) * 4, st, a); break;

@@ -26,6 +26,7 @@ int opt_lstm_skip0();
 int opt_lstm_xcd();
 int opt_gemm_small();
 int opt_lstm_tile();
+int opt_lstm_small4();
 int opt_lstm_small();
 int opt_gemm_pp();
 int opt_mfma_min();
