@@ -1134,7 +1134,7 @@ def test_resnet_stack_bit_exact_reduced(vfr, oracle, hw, blocks, width, T):
 @pytest.mark.gpu
 def test_resnet152_full_size_bit_exact_and_torch_fixture(vfr, oracle, golden):
     """f4 at FULL size: ResNet-152 (3 / 8 / 36 / 3, width 64, 224x224): frame 0 == the oracle bit for bit, both frames == fixture
-    G12 (the same network from torch.nn modules) to 1e-4 of the activation scale; a pass over 70 frames (two chunks of the frame
+    G12 (the same network from torch.nn modules) to 1e-4 of the activation scale; a pass over 170 frames (two chunks of the frame
     loop) reproduces the two-frame result row for row."""
     blocks, width = (3, 8, 36, 3), 64
     sd = synth.resnet_weights(blocks, width, seed=12)
@@ -1145,9 +1145,9 @@ def test_resnet152_full_size_bit_exact_and_torch_fixture(vfr, oracle, golden):
     assert got.shape == (2, 2048)
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want).max())))
     assert same(got[:1], oracle.resnet_pool(frames[:1], sd))
-    many = np.concatenate([frames] * 35)
-    got70 = vfr.resnet_pool(dev(many), packed)
-    assert torch.equal(got70[0::2], got[0:1].expand(35, -1)) and torch.equal(got70[1::2], got[1:2].expand(35, -1))
+    many = np.concatenate([frames] * 85)                                     # 170 frames: two chunks of the frame loop (chunk <= 160)
+    got170 = vfr.resnet_pool(dev(many), packed)
+    assert torch.equal(got170[0::2], got[0:1].expand(85, -1)) and torch.equal(got170[1::2], got[1:2].expand(85, -1))
 
 
 @pytest.mark.gpu

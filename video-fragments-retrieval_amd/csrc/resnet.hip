@@ -152,7 +152,7 @@ static ResPlan plan_resnet(int chunk, int H, int W, const int *blocks, int width
     }
     return p;
 }
-constexpr int RESNET_FRAME_CHUNK = 64;
+constexpr int RESNET_FRAME_CHUNK = 160;     // (64: layer3 GEMMs of 12 544 rows = half a round of 128-row tiles; 160: one DiDeMo video per pass)
 static int resnet_chunk(int T)
 {
     if (T <= RESNET_FRAME_CHUNK) return T;
