@@ -589,6 +589,13 @@ def test_bilstm_few_queries_vector_chain(vfr, oracle, normlang):
             vfr.set_option("lstm_small", 2)
         assert torch.equal(small.view(torch.int32), tiles.view(torch.int32)), B
         assert same(small, want[:B]), B
+        if B == 1:                                                    # one query of the model's shape: the four-wave weight stream vs the one-wave step
+            try:
+                vfr.set_option("lstm_small4", 0)
+                one_wave = vfr.bilstm_final(dev(tokens[:1]), *rest)
+            finally:
+                vfr.set_option("lstm_small4", 1)
+            assert torch.equal(small.view(torch.int32), one_wave.view(torch.int32))
 
 
 @pytest.mark.gpu
