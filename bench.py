@@ -10,7 +10,7 @@ One step = one pass of the hot path over one batch, inputs resident in HBM: clip
 videos (packed [n+1, 4096] fc7 features -> 100-d clip embeddings), BiLSTM query encoder over the query
 batch, own-video scores for ground truth, then the fused kernel that scores every query against every
 moment of every video, keeps the top-k and counts the rank of the best ground-truth moment for both IoU
-thresholds.  With N > 1 the 10k videos are sharded contiguously (strong scaling, BASELINE config 4), each
+thresholds.  With N > 1 the 10k videos are sharded contiguously (strong scaling), each
 rank encodes 1/N of the queries (all_gather), best-GT keys are all_reduce(MIN)'d, rank counts
 all_reduce(SUM)'d and the per-shard top-k lists all_gather'ed and merged (RCCL).
 
@@ -54,7 +54,7 @@ def parse():
                     help="vfr_set_option passthrough for parameter sweeps (results must not change: compare the checksums)")
     ap.add_argument("--host-feed", action="store_true",
                     help="also time the pass with the pooled features in pinned HOST memory (PCIe-inclusive; extra field, never `value`)")
-    ap.add_argument("--vgg-videos", type=int, default=24, help="videos of the extractor-loop sub-record (BASELINE config 3's loop)")
+    ap.add_argument("--vgg-videos", type=int, default=24, help="videos of the extractor-loop sub-record (BASELINE.md C3's loop)")
     ap.add_argument("--plant-alpha", type=float, default=0.5, help="noise scale of the planted-query sub-record (realistic_gt)")
     ap.add_argument("--cpu-queries", type=int, default=1024, help="queries of the batch the CPU oracle leg runs (against ALL videos)")
     ap.add_argument("--parity-ranks", type=int, default=64, help="queries whose ground-truth rank counts the oracle recomputes")
@@ -446,15 +446,15 @@ def _timed(fn, reps):
 
 
 def extras(args, dev, model, seg, ctx, clip_off, tokens, make_shard, ranks_of, out_f32, Nq, Nv, counts_all, ops):
-    """Sub-records measured after the timed region (never part of `value`): BASELINE config 5 (bf16 MFMA scoring, tolerance
-    against the fp32 result), the small query batches of config 2, and config 3's VGG19-fc7 extractor."""
+    """Sub-records measured after the timed region (never part of `value`): BASELINE.md C5 (bf16 MFMA scoring, tolerance
+    against the fp32 result), the small query batches of C2, and C3's VGG19-fc7 extractor."""
     from vfr_amd import _vfr, engine, synth
     ex = {}
     with torch.no_grad():
         emb = model.encode_clips(seg, ctx, clip_off)
         shard = make_shard(emb)
         Q = engine.encode_queries(model, tokens, dev, ops)
-        # ---- bf16 operands, fp32 accumulate (config 5): the same step with the scoring in bf16 mode ----
+        # ---- bf16 operands, fp32 accumulate (BASELINE.md C5): the same step with the scoring in bf16 mode ----
         old = _vfr.DEFAULT_SCORE_MODE
         try:
             _vfr.DEFAULT_SCORE_MODE = "bf16"
@@ -485,7 +485,7 @@ def extras(args, dev, model, seg, ctx, clip_off, tokens, make_shard, ranks_of, o
                       "R@1_R@10_R@100_f32": [float((r_f[0] < t).float().mean()) for t in (1, 10, 100)],
                       "R@1_R@10_R@100_bf16": [float((r_b[0] < t).float().mean()) for t in (1, 10, 100)],
                       "median_rank_f32_vs_bf16": [float(r_f[0].float().median()), float(r_b[0].float().median())]}
-        # ---- small query batches (BASELINE config 2: Nq in {1, 64, 1024}): query encoder + labels + scoring against the
+        # ---- small query batches (Nq in {1, 64, 1024}): query encoder + labels + scoring against the
         # resident clip bank (what a serving request costs once the corpus is embedded)
         small = {}
         for nq in (1, 64, 1024):
@@ -505,7 +505,7 @@ def extras(args, dev, model, seg, ctx, clip_off, tokens, make_shard, ranks_of, o
             ex["realistic_gt"] = realistic_gt(args, dev, emb, shard, ranks_of, Nq, counts_all)
         except IndexError as e:
             ex["realistic_gt"] = {"error": str(e)[:200]}
-    # ---- VGG19-fc7 extractor (config 3): one 150-frame video of 224x224 frames, full-width random weights ----
+    # ---- VGG19-fc7 extractor: one 150-frame video of 224x224 frames, full-width random weights ----
     try:
         cfgv = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
         g = torch.Generator(device=dev); g.manual_seed(7)
@@ -525,7 +525,7 @@ def extras(args, dev, model, seg, ctx, clip_off, tokens, make_shard, ranks_of, o
                      "ms_per_video": dt_v * 1e3, "frames_per_s": 150 / dt_v, "videos_per_s": 1 / dt_v,
                      "tflops": gflop / dt_v / 1e3, "frac_fp32_mfma_peak": gflop / dt_v / 1e3 / FP32_PEAK_TFLOPS,
                      "finite": bool(torch.isfinite(feat).all())}
-        # the LOOP of get_rgb_features.py:134-153 (BASELINE config 3 is "1k videos", not one): features.extract_dataset over
+        # the LOOP of get_rgb_features.py:134-153 (BASELINE.md C3 is "1k videos", not one): features.extract_dataset over
         # `--vgg-videos` synthetic videos of 900 decoded frames at 30 fps (-> 150 selected), decoder = a seeded frame store in host
         # memory (decode speed is the codec's, not ours), one .npy per video written to a scratch directory
         import tempfile

@@ -129,7 +129,7 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
  *                       re-scored with the exact chain, so every output is BIT-IDENTICAL to vfr_score_topk_f32
  *                       (shapes the pre-filter is not built for are simply handed to vfr_score_topk_f32; 1-8 queries -- a
  *                       serving request -- take a path of their own with lanes = clips / videos, equally exact);
- *   dtype VFR_MFMA_BF16 bf16 operands, fp32 accumulate (BASELINE config 5): count_lt from the approximate
+ *   dtype VFR_MFMA_BF16 bf16 operands, fp32 accumulate: count_lt from the approximate
  *                       distances, top-k = exact re-rank of the k + 28 best approximate candidates.  Needs D = 100,
  *                       max_clips <= 21, num_rank in {0, 2}, k <= 253; VFR_EUNSUPPORTED otherwise.
  * Arguments as vfr_score_topk_f32.

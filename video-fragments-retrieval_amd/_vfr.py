@@ -311,7 +311,7 @@ def score_own(Q: torch.Tensor, bank: VideoBank, own: torch.Tensor, eps: float = 
 
 
 # scoring mode of score_topk: "mfma" = fp32 MFMA pre-filter + exact re-scoring (bit-identical to "exact", the default),
-# "exact" = the exact VALU kernels only, "bf16" = bf16 MFMA operands, approximate (BASELINE config 5)
+# "exact" = the exact VALU kernels only, "bf16" = bf16 MFMA operands, approximate
 SCORE_MODES = {"exact": None, "mfma": 0, "bf16": 1}
 MFMA_BANK_READY = 0x100                    # include/vfr.h VFR_MFMA_BANK_READY
 DEFAULT_SCORE_MODE = os.environ.get("VFR_SCORE_MODE", "mfma")

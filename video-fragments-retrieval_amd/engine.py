@@ -586,7 +586,7 @@ def gather_merge_topk(od, oi, ops, world, extra=None):
 class TorchCpuOps:
     """The same provider interface on CPU tensors with plain torch ops.
 
-    This is the CPU *device* of the API (``evaluate(..., device='cpu')``, BASELINE config 0, and the
+    This is the CPU *device* of the API (``evaluate(..., device='cpu')``, BASELINE.md C1, and the
     multi-rank plumbing tests under gloo) -- it is selected only by an explicit CPU device, never as a
     substitute when a ROCm device was asked for."""
 

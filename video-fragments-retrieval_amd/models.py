@@ -11,7 +11,7 @@ Dispatch inside ``forward``:
   ``main.py:66`` runs on our kernels too; ``models.HIP_TRAINING = False`` switches this path back to the ``torch.nn``
   sub-modules (A/B checks).
 * input on the CPU  ->  the same ``torch.nn`` sub-modules (an ``nn.Module`` has to run where its tensors
-  live; BASELINE config 0 is a CPU run).
+  live; BASELINE.md C1 is a CPU run).
 
 ``encode_clips`` / ``encode_queries`` are the batched entry points the evaluators use: a whole corpus /
 a whole query batch per call, with the factored clip encoder that never materialises the ``[n, 2F+2]``
