@@ -441,3 +441,22 @@ def test_extract_dataset_resume_and_missed_bookkeeping(tmp_path, monkeypatch):
     assert written == ["v0", "v1", "v4"] and (ft / "resnet152_ft_v1.npy").exists() and len(calls) == 3
     with pytest.raises(ValueError):
         features.extract_dataset(info, decoder, ft, None, model_type="resnet50", missed_path=missed_file)
+
+
+def test_resnet_plan_and_frame_selection_host_side(oracle):
+    """f4 host logic: the product's convolution order for vfr_resnet_pool_f32 == the oracle's execution plan (names, count =
+    1 + sum(3 n + 1)); features.select_frames gathers on the host, passes a pre-selected clip through (fps <= 0) and keeps dtype."""
+    from vfr_amd import _vfr, features
+    for blocks in ((3, 8, 36, 3), (1, 2, 2, 1), (2, 1, 3, 2)):
+        mine = _vfr.resnet_conv_plan(blocks, 64)
+        theirs = oracle.resnet_conv_plan(blocks, 64)
+        assert [m for m in mine] == [(t[0], t[1]) for t in theirs]
+        assert len(mine) == 1 + sum(3 * n + 1 for n in blocks)
+        sd = synth.resnet_weights(blocks, 4, seed=2)
+        for conv, bn in mine:
+            assert conv + ".weight" in sd and all(f"{bn}.{k}" in sd for k in ("weight", "bias", "running_mean", "running_var"))
+    fr = np.arange(900 * 2 * 2 * 3, dtype=np.uint8).reshape(900, 2, 2, 3)
+    sel = features.select_frames(fr, 30.0, 6)
+    idx = features.sample_frames(900, 30.0, 6)
+    assert sel.dtype == torch.uint8 and sel.shape == (150, 2, 2, 3) and np.array_equal(sel.numpy(), fr[idx])
+    assert features.select_frames(fr[:7], 0.0, 6).shape == (7, 2, 2, 3)
