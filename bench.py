@@ -85,7 +85,7 @@ def site_work(site, cfg):
     rows = cfg["lstm_rows_per_step"]
     per_scoring = 2 * n * D + n + 2 * M
     world = cfg.get("world", 1)
-    if world > 1:
+    if world > 1 or cfg.get("sharded_protocol"):
         # sharded pass (engine.sharded_search_fused): the top-k sample pass over s_r videos and the seeded main pass over the rest
         # of the shard are both `score_fused` launches (their work averaged), the sample videos' rank-only pass is `score_rank`
         s_r = min(Nv, -(-256 // world))
@@ -203,7 +203,15 @@ def main():
     backend = os.environ.get("VFR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # VFR_BENCH_FORCE_DIST=1 (rehearsal, one rank): a world-size-1 RCCL group runs the complete sharded protocol -- the sample
+    # pass, the three packed all-gathers, the merges -- so the multi-GPU code path executes on RCCL on a one-GPU box; the
+    # checksums must equal the plain run's
+    force_dist = world == 1 and bool(os.environ.get("VFR_BENCH_FORCE_DIST"))
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        engine.FORCE_COLLECTIVES = True
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -305,6 +313,7 @@ def main():
     dt = time.perf_counter() - t0
     _vfr.set_option("profile", 0)
     sites = _vfr.profile_read(reset=True)
+    engine.FORCE_COLLECTIVES = False                 # the sub-records after the timed region are plain single-GPU passes
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -353,7 +362,7 @@ def main():
     rev_rows = sum(1 + int((qlen > T_ - 1 - s).sum()) for s in range(T_)) / T_
     cfg = dict(Bq=Bq, C=C_loc, Nv=hi - lo, H=model.hidden_size, E=100, F=F, hid=500, D=100,
                n=int(round(n_eff)), Nq=Nq, T=T_, lstm_rows_per_step=(Bq + 1) + rev_rows,
-               vocab=int(sd["word_embedding.weight"].shape[0]), world=world)
+               vocab=int(sd["word_embedding.weight"].shape[0]), world=world, sharded_protocol=force_dist)
     if not sites:                                  # VFR_BENCH_NO_SITES rehearsal: nothing to attribute
         print(json.dumps({"ms_per_step": ms_step, "value": value, "n_gpus": world, "note": "site events off (rehearsal)"}))
         if dist is not None:
@@ -367,7 +376,7 @@ def main():
         # no site may claim more than the chip can do: a violation is an accounting bug, not a result.  Single-GPU (the
         # validated formulas) it stops the bench; a sharded run drops the figure and says so rather than lose the measurement
         if tf is not None and tf > FP32_PEAK_TFLOPS:
-            assert world > 1, f"site {name}: {tf:.1f} TFLOP/s > fp32 peak -- wrong work formula"
+            assert world > 1 or force_dist, f"site {name}: {tf:.1f} TFLOP/s > fp32 peak -- wrong work formula"
             accounting_notes.append(f"{name}: work formula gave {tf:.1f} TFLOP/s > peak, figure dropped")
             tf = tf_exec = None
         kernels[name] = {"kernel": KERNEL_OF_SITE.get(name, name), "ms_per_step": ms / args.steps,
@@ -420,6 +429,9 @@ def main():
         "ranks_checksum": int(ranks.sum()), "topk_checksum": int(out[2].sum()) if out[2] is not None else None,
         "roofline": roofline, "scorer": scorer, "kernels": kernels,
     }
+    if force_dist:
+        line["rehearsal"] = ("VFR_BENCH_FORCE_DIST: ONE rank ran the sharded protocol (sample pass, three packed all-gathers, "
+                             f"merges) through a world-size-1 '{backend}' process group; not the headline configuration")
     if accounting_notes:
         line["accounting_notes"] = accounting_notes
     if host_feed is not None:

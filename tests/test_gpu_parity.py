@@ -2,6 +2,7 @@
 seeded inputs.  Bar: bit-exact (the kernels implement the oracle's canonical fp32 evaluation order), and
 within 1e-4 / identical top-k against the reference's own golden vectors."""
 import json
+import os
 import random
 from pathlib import Path
 
@@ -822,6 +823,27 @@ def test_exchange_key_helpers_match_cpu_provider(vfr):
                                    torch.from_numpy(base).to(DEV), torch.from_numpy(sel).to(DEV), Nq)
             assert torch.equal(got.cpu(), want)
             assert int(got[0, sel[0]]) == engine.KEY_INF
+
+
+@pytest.mark.gpu
+def test_rccl_world1_runs_the_sharded_protocol(vfr):
+    """The exchange steps of the sharded pass through REAL RCCL calls on this one GPU: a world-size-1 "nccl"
+    process group in a child process (tests/rccl_world1_worker.py) with engine.FORCE_COLLECTIVES, so the packed all-gathers
+    (``all_gather_into_tensor`` on device int64 / fp32 rows) and the MIN / SUM all-reduces are issued exactly as on N GPUs.
+    evaluate() -- the three-collective fused protocol -- and validate_epoch() -- 11 thresholds, five-collective form -- must
+    equal the plain single-GPU pass: dicts, top-100 ids and distances."""
+    import json
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_world1_worker.py")
+    res = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("RCCL_WORLD1 ")][-1]
+    out = json.loads(line[len("RCCL_WORLD1 "):])
+    assert out["backend"] == "nccl" and out["gather_form"] == "tensor"
+    assert out["fused_collectives"] == {"all_gather_into_tensor": 3, "all_reduce": 0}      # evaluate(): three collectives
+    assert out["calls"]["all_reduce"] > 0                                                   # validate_epoch(): MIN + SUM folds
+    assert out["evaluate_equal"] and out["validate_equal"] and out["topk_ids_equal"] and out["topk_dist_equal"]
 
 
 @pytest.mark.gpu

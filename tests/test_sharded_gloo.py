@@ -20,13 +20,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, clips, out_dir, sample=256):
+def _worker(rank, world, port, clips, out_dir, sample=256, force=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from vfr_amd import engine
         from vfr_amd import evaluate as vevaluate
+        engine.FORCE_COLLECTIVES = force       # one rank running the whole exchange protocol (the RCCL rehearsal's switch)
         engine.SAMPLE_VIDEOS = sample          # small sample: both the sample part and the seeded main part are non-empty
         p = problem(37, 23, clips, feat_dim=64, hidden=16)          # odd sizes: uneven shards, padded query split
         ds = MemoryDataset(p["seg"], p["ctx"], p["counts"], p["tokens"], p["own"], p["times"])
@@ -42,11 +43,11 @@ def _worker(rank, world, port, clips, out_dir, sample=256):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("clips,sample", [(6, 256), ("didemo", 256), ("didemo", 8)])
-def test_two_rank_sharded_evaluate_equals_single_process(tmp_path, clips, sample):
+@pytest.mark.parametrize("clips,sample,world", [(6, 256, 2), ("didemo", 256, 2), ("didemo", 8, 2), ("didemo", 8, 1)])
+def test_two_rank_sharded_evaluate_equals_single_process(tmp_path, clips, sample, world):
+    """world = 1: ONE rank with engine.FORCE_COLLECTIVES -- the form the GPU suite runs over RCCL on a one-GPU box."""
     from vfr_amd import evaluate as vevaluate
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), clips, str(tmp_path), sample), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), clips, str(tmp_path), sample, world == 1), nprocs=world, join=True)
     p = problem(37, 23, clips, feat_dim=64, hidden=16)
     ds = MemoryDataset(p["seg"], p["ctx"], p["counts"], p["tokens"], p["own"], p["times"])
     vi, li = ds.iterators()

@@ -86,6 +86,18 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
+# Rehearsal switch: with ONE rank the exchange steps are skipped (nothing to exchange).  Setting this makes a world-size-1
+# process group run the full sharded protocol -- sample pass, the packed all-gathers, MIN / SUM folds, merges -- so that the
+# RCCL code path can be executed, and checked against the plain single-GPU pass, on a one-GPU box
+# (tests/test_gpu_parity.py::test_rccl_world1_runs_the_sharded_protocol, bench.py VFR_BENCH_FORCE_DIST=1).
+FORCE_COLLECTIVES = False
+
+
+def _group(world):
+    """The process group the exchange steps of a ``world``-rank pass go through, or None when there is nothing to exchange."""
+    return _dist() if (world > 1 or FORCE_COLLECTIVES) else None
+
+
 def _all_gather_rows(dist, out, mine):
     """out[g] <- rank g's ``mine`` for a contiguous ``out [world, *mine.shape]``: ONE collective straight into the buffer
     (``all_gather_into_tensor``; the list form makes the RCCL backend gather into a scratch tensor and copy the parts out).
@@ -257,7 +269,7 @@ def corpus_from_embeddings(emb, counts, device, ops=None, rank=0, world=1) -> Co
 def encode_queries(model, tokens, device, ops=None, rank=0, world=1):
     """Query embeddings for the whole batch; with world > 1 each rank encodes a slice and they are gathered."""
     ops = ops or HipOps()
-    dist = _dist() if world > 1 else None
+    dist = _group(world)
     if dist is None:
         return ops.encode_queries(model, tokens.to(device))
     Nq = tokens.shape[0]
@@ -414,7 +426,7 @@ def best_positive_keys(shard: CorpusShard, Q, gt: QueryGT, ops, world=1, reduce=
         keys = ops.gt_best_keys(sc, gt.labels, gt.base, gt.sel, gt.num_queries)
     else:
         keys = torch.full((gt.num_thresholds, gt.num_queries), KEY_INF, dtype=torch.int64, device=shard.device)
-    dist = _dist() if world > 1 else None
+    dist = _group(world)
     if dist is not None and reduce:
         dist.all_reduce(keys, op=dist.ReduceOp.MIN)
     return keys
@@ -428,7 +440,7 @@ def corpus_ranks(shard: CorpusShard, Q, own_global, labels, ops=None, k=0, world
     in the reference (Q3)."""
     ops = ops or HipOps()
     gt = gt if gt is not None else prepare_gt(shard, own_global, labels)
-    fused = world > 1 and k > 0 and gt.num_thresholds == 2 and _dist() is not None
+    fused = k > 0 and gt.num_thresholds == 2 and _group(world) is not None
     keys = best_positive_keys(shard, Q, gt, ops, world, reduce=not fused)
     state = {}
 
@@ -498,7 +510,7 @@ def sharded_search(shard: CorpusShard, Q, k, rank_dist, rank_idx, ops, world=1, 
     per-rank sample lists are all-gathered and merged into the GLOBAL sample top-k, whose k-th key seeds every
     rank's main pass over the rest of its shard (``thr_seed``); the final lists (main parts + the sample list) are
     all-gathered and merged once more.  Rank counts are summed with one all_reduce."""
-    dist = _dist() if world > 1 else None
+    dist = _group(world)
     if dist is None or k == 0:
         od, oi, counts = ops.score_topk(Q, shard.bank, k, rank_dist, rank_idx, workspace=workspace)
         if dist is not None and counts is not None:
