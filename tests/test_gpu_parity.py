@@ -571,8 +571,9 @@ def test_prefilter_bank_products_reused_only_while_valid(vfr, mode):
 @pytest.mark.gpu
 @pytest.mark.parametrize("normlang", [False, True])
 def test_bilstm_few_queries_vector_chain(vfr, oracle, normlang):
-    """Batches of 1-4 queries (a serving request) take the vector-chain LSTM step (`lstm_small`): same bits as the MFMA tile
-    path forced on the same rows, and as the oracle; incl. an all-pad query and the normalised-length embedding."""
+    """Batches of 1-4 queries (a serving request) take the vector-chain LSTM step (`lstm_small`; one or two queries: the
+    single-launch sequence kernel, `lstm_persist`): same bits as the MFMA tile path forced on the same rows, and as the
+    oracle; incl. an all-pad query and the normalised-length embedding."""
     sd = synth.model_weights(4096, seed=13, normalize_lang=normlang)
     tokens = synth.query_tokens(4, seed=13)
     tokens[2, :] = 0                                                  # an all-pad query
@@ -590,13 +591,26 @@ def test_bilstm_few_queries_vector_chain(vfr, oracle, normlang):
             vfr.set_option("lstm_small", 2)
         assert torch.equal(small.view(torch.int32), tiles.view(torch.int32)), B
         assert same(small, want[:B]), B
-        if B == 1:                                                    # one query of the model's shape: the four-wave weight stream vs the one-wave step
+        if B <= 2:
+            # one or two queries: `small` above ran the whole sequence in ONE launch (weights resident in LDS, h handed from
+            # workgroup to workgroup as tagged granules: lstm_persist); the same batch one launch per step, and the
+            # single-launch form again (its granule buffers are re-zeroed every call)
             try:
-                vfr.set_option("lstm_small4", 0)
-                one_wave = vfr.bilstm_final(dev(tokens[:1]), *rest)
+                vfr.set_option("lstm_persist", 0)
+                vfr.set_option("lstm_small", 4)
+                steps = vfr.bilstm_final(dev(tokens[:B]), *rest)
+                if B == 1:                                                # the four-wave weight stream vs the one-wave step
+                    vfr.set_option("lstm_small4", 0)
+                    one_wave = vfr.bilstm_final(dev(tokens[:1]), *rest)
+                    assert torch.equal(steps.view(torch.int32), one_wave.view(torch.int32))
             finally:
                 vfr.set_option("lstm_small4", 1)
-            assert torch.equal(small.view(torch.int32), one_wave.view(torch.int32))
+                vfr.set_option("lstm_persist", 1)
+                vfr.set_option("lstm_small", 2)
+            assert torch.equal(small.view(torch.int32), steps.view(torch.int32)), B
+            for _ in range(3):
+                again = vfr.bilstm_final(dev(tokens[:B]), *rest)
+                assert torch.equal(small.view(torch.int32), again.view(torch.int32)), B
 
 
 @pytest.mark.gpu

@@ -389,8 +389,259 @@ __global__ __launch_bounds__(64 * (S4_NL + 1), 1) void lstm_step_small4_kernel(S
     }
 }
 
+// ---- one or two queries, the whole sequence in ONE launch with the weights resident in LDS ---------------------------
+// The per-step kernels above re-read all 35 MB of [W_ih | W_hh] (both directions) every step: 13 us per step whatever is done
+// about the stream, 20 dependent launches = 0.27 ms of a 0.49 ms serving request.  Here a workgroup owns 8 hidden units of
+// one direction = 32 gate columns and keeps their (E + H) x 32 weights in LDS for all T steps (chunk-major, 140.8 KB at the
+// model's shape: 2 x 125 workgroups, one per CU); per step its first wave runs the 32 canonical chains -- lane = gate column,
+// lanes 32..63 the second query on the same weights; the E-part before the previous step's h is needed --, finishes its 8
+// cells (c stays in a register for the whole sequence) and publishes the 8 new h values as 8-byte {step tag, value} granules
+// (agent-scope relaxed atomic stores: write-through, untorn); every workgroup of the direction then sweeps the H granules of
+// the step with agent-scope atomic loads until every tag matches -- the data is the flag, no counter, no fence, no plain load
+// of handed-off bytes (MI355X guide, Guideline 16 form R2).  Two granule buffers alternate: a workgroup can run at most one
+// step ahead of the slowest one (it needs that one's h to go further).  Same chains in the same order as the step kernels:
+// identical bits (tests: lstm_persist 0 vs 1, and the oracle).
+// Every workgroup must be resident (the host checks grid <= CU count; 150 KB of LDS = one workgroup per CU); the sweeps are
+// bounded: a workgroup that gives up raises a.err, poisons its outputs with NaN and leaves, and so do all the others.
+typedef __attribute__((address_space(1))) unsigned long long seq_gu64;
+struct SeqLstm {
+    const float *X;                       // [B*T, E] embedded tokens
+    const float *Wih[2], *Whh[2], *bih[2], *bhh[2];
+    unsigned long long *hg;               // granules [2 buffers][2 directions][B][H], zeroed before the launch
+    float *hout;                          // [B, 2H]: the final h (direction d at column d*H)
+    unsigned *err;                        // raised when a sweep gave up (zeroed before the launch)
+    int B, T, E, H;
+    const float *Wfc, *bfc;               // lang_fc fused behind the last step (nullptr: the caller runs it): [D, 2H], [D]
+    float *out;                           // [B, D]
+    int D;
+};
+constexpr int SEQ_WSTRIDE = 33 * 4;       // floats per chunk row: 32 columns x 4 k's + 4 of padding (staging writes conflict-free)
+constexpr unsigned SEQ_MAX_SPINS = 1u << 17;
+
+template <int RB>
+__global__ __launch_bounds__(256, 1) void lstm_seq_small_kernel(SeqLstm a)
+{
+    constexpr int NG = 16 * RB;           // granule loads per lane and sweep: covers B x H <= 1024 x RB
+    extern __shared__ __attribute__((aligned(16))) float seq_lds[];
+    const int E = a.E, H = a.H, nce = E / 4, nch = (E + H) / 4;
+    float *Wl = seq_lds;                  // [nch][33][4]
+    float *xh = Wl + (size_t)nch * SEQ_WSTRIDE;      // [RB][E + H]: this step's embedded token | the previous step's h
+    float *pre = xh + RB * (E + H);       // [RB][4][8] gate pre-activations
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nblk = (H + 7) / 8, d = blockIdx.x / nblk, u0 = (blockIdx.x % nblk) * 8;
+    // ---- weights of the 32 columns -> LDS (all four waves; consecutive lanes = consecutive chunks of one column) ----
+    {
+        const int total = 32 * nch;
+        for (int i0 = 0; i0 < total; i0 += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int i = i0 + 256 * j + tid;
+                i = i < total ? i : total - 1;
+                const int c = i / nch, ch = i - c * nch;
+                int unit = u0 + (c & 7);
+                unit = unit < H ? unit : H - 1;
+                const size_t row = (size_t)(c >> 3) * H + unit;
+                v[j] = ch < nce ? *reinterpret_cast<const float4 *>(a.Wih[d] + row * E + 4 * ch)
+                                : *reinterpret_cast<const float4 *>(a.Whh[d] + row * H + 4 * (ch - nce));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int i = i0 + 256 * j + tid;
+                i = i < total ? i : total - 1;
+                const int c = i / nch, ch = i - c * nch;
+                *reinterpret_cast<float4 *>(Wl + (size_t)ch * SEQ_WSTRIDE + c * 4) = v[j];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid >= 64) return;                // the sequence is one wave's work
+    const int col = lane & 31, r = lane >> 5, gate = col >> 3, ul = col & 7;
+    const bool rowok = r < RB && r < a.B;
+    const int rr = rowok ? r : 0;
+    const int unit = u0 + ul, uc = unit < H ? unit : H - 1;
+    const float *wl = Wl + col * 4;
+    const size_t gdir = (size_t)a.B * H;                                   // granules per (buffer, direction)
+    // cell lanes: column lanes of gate 0 (col < 8) finish unit u0 + col of row r
+    const bool cell = col < 8 && rowok;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f}, cst = 0.0f;
+    if (cell) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bsum[g] = a.bih[d][g * H + uc] + a.bhh[d][g * H + uc];
+    }
+    bool dead = false;
+    float acc = 0.0f;
+    const float *xrow = xh + rr * (E + H);
+    // chunks [c0, c1) of the lane's chain: groups of 5 chunks in two register sets, the next group's LDS reads (weights: one
+    // 16-byte read per lane; inputs: broadcast) issued before the current group's 20 dependent fmas
+    auto chain = [&](int c0, int c1) {
+        constexpr int G = 5;
+        float4 w0[G], x0[G], w1[G], x1[G];
+        auto load = [&](float4 (&w)[G], float4 (&x)[G], int c) {
+            c = c + G <= c1 ? c : c1 - G;                        // (the group past the end: re-read the last one, unused)
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                w[j] = *reinterpret_cast<const float4 *>(wl + (size_t)(c + j) * SEQ_WSTRIDE);
+                x[j] = *reinterpret_cast<const float4 *>(xrow + 4 * (c + j));
+            }
+        };
+        auto fma5 = [&](const float4 (&w)[G], const float4 (&x)[G]) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                acc = __builtin_fmaf(x[j].x, w[j].x, acc); acc = __builtin_fmaf(x[j].y, w[j].y, acc);
+                acc = __builtin_fmaf(x[j].z, w[j].z, acc); acc = __builtin_fmaf(x[j].w, w[j].w, acc);
+            }
+        };
+        int ch = c0;
+        if (c1 - c0 >= G) {
+            load(w0, x0, ch);
+            while (true) {
+                load(w1, x1, ch + G);
+                __builtin_amdgcn_sched_barrier(0);
+                fma5(w0, x0);
+                ch += G;
+                if (ch + G > c1) break;
+                load(w0, x0, ch + G);
+                __builtin_amdgcn_sched_barrier(0);
+                fma5(w1, x1);
+                ch += G;
+                if (ch + G > c1) break;
+            }
+        }
+        for (; ch < c1; ++ch) {
+            const float4 w = *reinterpret_cast<const float4 *>(wl + (size_t)ch * SEQ_WSTRIDE);
+            const float4 x = *reinterpret_cast<const float4 *>(xrow + 4 * ch);
+            acc = __builtin_fmaf(x.x, w.x, acc); acc = __builtin_fmaf(x.y, w.y, acc);
+            acc = __builtin_fmaf(x.z, w.z, acc); acc = __builtin_fmaf(x.w, w.w, acc);
+        }
+    };
+    // embedded tokens: the next step's are requested a step ahead (RB * E <= 256: four registers per lane)
+    float xn[4];
+    auto xload = [&](int step) {
+        const int t = d ? a.T - 1 - step : step;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int i = lane + 64 * j;
+            i = i < RB * E ? i : RB * E - 1;
+            const int xr = i / E, k = i - xr * E;
+            xn[j] = a.X[((size_t)(xr < a.B ? xr : 0) * a.T + (t < 0 ? 0 : (t >= a.T ? a.T - 1 : t))) * E + k];
+        }
+    };
+    xload(0);
+    for (int step = 0; step < a.T; ++step) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int i = lane + 64 * j;
+            i = i < RB * E ? i : RB * E - 1;
+            const int xr = i / E, k = i - xr * E;
+            xh[xr * (E + H) + k] = xn[j];
+        }
+        xload(step + 1 < a.T ? step + 1 : step);
+        acc = 0.0f;
+        chain(0, nce);
+        if (step > 0 && !dead) {
+            // ---- sweep the H granules of step - 1 (tag = step) of this direction until all are there ----
+            seq_gu64 *gp = (seq_gu64 *)(a.hg + ((size_t)((step - 1) & 1) * 2 + d) * gdir);
+            const int n = a.B * H;
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+                unsigned long long gv[NG];
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    const int g = lane + 64 * j;
+                    gv[j] = __hip_atomic_load(gp + (g < n ? g : n - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    int g = lane + 64 * j;                               // (past the end: the last granule again, same value)
+                    g = g < n ? g : n - 1;
+                    ok &= (unsigned)(gv[j] >> 32) == (unsigned)step;
+                    const int gr = g / H;
+                    xh[gr * (E + H) + E + (g - gr * H)] = __uint_as_float((unsigned)gv[j]);
+                }
+                if (__all(ok)) break;
+                if (spins >= SEQ_MAX_SPINS) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!dead) chain(nce, nch);
+        }
+        if (r < RB) pre[(r * 4 + gate) * 8 + ul] = acc;
+        float hn = 0.0f;
+        if (cell) {
+            const float *pr = pre + r * 32 + ul;
+            const float ig = c_sigmoidf(pr[0] + bsum[0]);
+            const float fg = c_sigmoidf(pr[8] + bsum[1]);
+            const float gg = c_tanhf(pr[16] + bsum[2]);
+            const float og = c_sigmoidf(pr[24] + bsum[3]);
+            cst = __builtin_fmaf(fg, cst, ig * gg);
+            hn = og * c_tanhf(cst);
+            if (dead) hn = __uint_as_float(0x7fc00000u);
+            if (unit < H) {
+                if (step + 1 < a.T || a.Wfc) {
+                    seq_gu64 *gq = (seq_gu64 *)(a.hg + ((size_t)(step & 1) * 2 + d) * gdir + (size_t)r * H + unit);
+                    __hip_atomic_store(gq, ((unsigned long long)(unsigned)(step + 1) << 32) | __float_as_uint(hn),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (step + 1 == a.T) a.hout[(size_t)r * 2 * H + (size_t)d * H + unit] = hn;
+            }
+        }
+    }
+    // ---- lang_fc behind the last step: workgroup o < D gathers the final [h_fwd | h_bwd] of every row (the granules of step
+    // T - 1, tag T, both directions) and ONE lane per row runs output o's chain over 2H (k ascending from zero, then + bias:
+    // gemm_nt's order) -- 4 us instead of a launch + a 32-row MFMA tile (0.05 ms) ----
+    if (a.Wfc && (int)blockIdx.x < a.D) {
+        const int o = blockIdx.x, K2 = 2 * H;
+        float *wrow = seq_lds;                           // [2H]        (the weight slices are no longer needed)
+        float *hfin = seq_lds + K2;                      // [RB][2H]
+        for (int i = lane; i < K2 / 4; i += 64)
+            *reinterpret_cast<float4 *>(wrow + 4 * i) = *reinterpret_cast<const float4 *>(a.Wfc + (size_t)o * K2 + 4 * i);
+        if (!dead) {
+            const size_t gb = (size_t)((a.T - 1) & 1) * 2 * gdir;
+            const int n = a.B * H;
+            for (int dd = 0; dd < 2 && !dead; ++dd) {
+                seq_gu64 *gp = (seq_gu64 *)(a.hg + gb + (size_t)dd * gdir);
+                for (unsigned spins = 0;; ++spins) {
+                    bool ok = true;
+                    unsigned long long gv[NG];
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) {
+                        const int g = lane + 64 * j;
+                        gv[j] = __hip_atomic_load(gp + (g < n ? g : n - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) {
+                        int g = lane + 64 * j;
+                        g = g < n ? g : n - 1;
+                        ok &= (unsigned)(gv[j] >> 32) == (unsigned)a.T;
+                        const int gr = g / H;
+                        hfin[gr * K2 + dd * H + (g - gr * H)] = __uint_as_float((unsigned)gv[j]);
+                    }
+                    if (__all(ok)) break;
+                    if (spins >= SEQ_MAX_SPINS) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
+        if (lane < RB && lane < a.B) {
+            const float *hp = hfin + lane * K2;
+            float s = 0.0f;
+#pragma unroll 8
+            for (int k4 = 0; k4 < K2 / 4; ++k4) {
+                const float4 w = *reinterpret_cast<const float4 *>(wrow + 4 * k4);
+                const float4 x = *reinterpret_cast<const float4 *>(hp + 4 * k4);
+                s = __builtin_fmaf(x.x, w.x, s); s = __builtin_fmaf(x.y, w.y, s);
+                s = __builtin_fmaf(x.z, w.z, s); s = __builtin_fmaf(x.w, w.w, s);
+            }
+            s = s + a.bfc[o];
+            a.out[(size_t)lane * a.D + o] = dead ? __uint_as_float(0x7fc00000u) : s;
+        }
+    }
+    if (dead && lane == 0) atomicOr(a.err, 1u);
+}
+
 struct LstmWs {
     float *X, *gates, *c, *c2, *hcat, *hcat2, *hfinal, *xv, *wperm, *ptab, *wt;
+    unsigned long long *hg;               // persistent sequence kernel: [16 B error word | 2 x 2 x B x H granules]
     int *tokidx;
     int64_t *tok_ext;
     int *len, *row_of, *xrow, *mcount, *hist;
@@ -424,6 +675,7 @@ static LstmWs carve(void *base, int64_t B, int T, int E, int H, int vocab)
         w.tokidx = reinterpret_cast<int *>(take_b(R * T * sizeof(int)));
     }
     if (B <= 4) w.wt = take((size_t)2 * (E + H) * 4 * H);       // k-major weights of the vector-chain step (a few queries)
+    if (B <= 2) w.hg = reinterpret_cast<unsigned long long *>(take_b(16 + (size_t)4 * B * H * sizeof(unsigned long long)));
     w.total = off;
     return w;
 }
@@ -469,6 +721,35 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
                            E, w.X);
         }
         VFR_CHECK_LAUNCH("embed_kernel");
+        // one or two queries at a shape whose 32-column weight slices fit a CU's LDS: the whole sequence in one launch
+        const size_t seq_lds = ((size_t)((E + H) / 4) * vfr::SEQ_WSTRIDE + (size_t)(B <= 1 ? 1 : 2) * (H + E + 32)) * sizeof(float);
+        const int seq_grid = 2 * (int)vfr::cdiv(H, 8);
+        if (vfr::opt_lstm_persist() && B <= 2 && w.hg && H <= 1024 && 2 * E <= 256 && (((uintptr_t)Wfc) & 15) == 0 && seq_lds <= 160 * 1024 && seq_grid <= vfr::device_cu_count()) {
+            const size_t gbytes = 16 + (size_t)4 * B * H * sizeof(unsigned long long);
+            if (hipMemsetAsync(w.hg, 0, gbytes, st) != hipSuccess)
+                return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: buffer initialisation failed");
+            // lang_fc rides in the same launch when every output gets a workgroup and the row fits beside the gathered h
+            const bool fc_in = D <= seq_grid && (size_t)(1 + (B <= 1 ? 1 : 2)) * 2 * H * sizeof(float) <= seq_lds;
+            vfr::SeqLstm a{w.X, {Wih_f, Wih_b}, {Whh_f, Whh_b}, {bih_f, bih_b}, {bhh_f, bhh_b}, w.hg + 2, w.hcat,
+                           reinterpret_cast<unsigned *>(w.hg), (int)B, T, E, H, fc_in ? Wfc : nullptr, bfc, out, D};
+            {
+            vfr::ProfScope prof(vfr::SITE_GEMM_LSTM_REC, st);
+            static bool attr_done[2] = {false, false};
+            if (B <= 1) {
+                if (!attr_done[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vfr::lstm_seq_small_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[0] = true; }
+                hipLaunchKernelGGL(vfr::lstm_seq_small_kernel<1>, dim3((unsigned)seq_grid), dim3(256), seq_lds, st, a);
+            } else {
+                if (!attr_done[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vfr::lstm_seq_small_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[1] = true; }
+                hipLaunchKernelGGL(vfr::lstm_seq_small_kernel<2>, dim3((unsigned)seq_grid), dim3(256), seq_lds, st, a);
+            }
+            }
+            VFR_CHECK_LAUNCH("lstm_seq_small_kernel");
+            if (fc_in) return VFR_OK;
+            vfr::GemmArgs g{};
+            g.A = w.hcat; g.lda = 2 * H; g.W = Wfc; g.ldw = 2 * H; g.out = out; g.ldo = D; g.M = B; g.N = D; g.K = 2 * H;
+            g.bias = bfc; g.epi = vfr::EPI_BIAS; g.site = vfr::SITE_GEMM_LANG_FC;
+            return vfr::gemm_nt(g, st);
+        }
         float *wt[2] = {w.wt, w.wt + (size_t)(E + H) * 4 * H};
         {
         vfr::ProfScope prof(vfr::SITE_GEMM_LSTM_IN, st);

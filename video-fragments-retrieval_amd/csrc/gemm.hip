@@ -430,7 +430,46 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #pragma unroll
         for (int i = 0; i < NW; ++i) rw[i] = *reinterpret_cast<const float4 *>(bw + (second ? woff2[i] : woff1[i]));
     };
-    const int nk_full = LSTM ? nk1 + (g.K2 + MBK - 1) / MBK
+    // LSTM step on the projection table (K == 0) with a short remainder of the recurrent segment (H = 1000: 31 K-tiles + 8):
+    // the remainder does not get a K-tile of its own (a shifted-back tile is 24 zero products in 32 -- 2.3 % of the launch's
+    // MFMAs); its <= 2 k-slices are fetched as MFMA fragments straight from global memory at the head of the kernel and run
+    // after the last full tile -- the same k-ascending chain, bit for bit.
+    const int ktail = (LSTM && !PP && g.K == 0 && g.K2 > MBK && (g.K2 % MBK) != 0 && (g.K2 % MBK) <= 8) ? g.K2 % MBK : 0;
+    constexpr int TI_ = MI ? 2 * MI : 1;
+    float tfa[2][TI_], tfb[2][4];
+    if (LSTM && ktail) {
+        const int kb = g.K2 - ktail + (lane >> 4);
+#pragma unroll
+        for (int ti = 0; ti < TI_; ++ti) {
+            const int64_t row = m0 + wm * (16 * TI_) + ti * 16 + (lane & 15);
+            const int64_t ma = row < Mrows ? row : Mrows - 1;
+            const float *pa = g.A2 + (ma >= Mprev ? 0 : ma) * g.lda2 + kb;
+            tfa[0][ti] = pa[0];
+            tfa[1][ti] = ktail > 4 ? pa[4] : 0.0f;
+        }
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            int unit = by * 32 + wn * 16 + (lane & 15);
+            unit = unit < g.lstm_H ? unit : g.lstm_H - 1;
+            const float *pw = g.W2 + ((int64_t)tj * g.lstm_H + unit) * g.ldw2 + kb;
+            tfb[0][tj] = pw[0];
+            tfb[1][tj] = ktail > 4 ? pw[4] : 0.0f;
+        }
+    }
+    auto tail_mfma = [&]() {
+        if (LSTM && ktail) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (s == 1 && ktail <= 4) break;
+#pragma unroll
+                for (int ti = 0; ti < TI_; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 4; ++tj)
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(tfa[s][ti], tfb[s][tj], acc[ti][tj], 0, 0, 0);
+            }
+        }
+    };
+    const int nk_full = LSTM ? nk1 + (ktail ? g.K2 / MBK : (g.K2 + MBK - 1) / MBK)
                              : CONV ? (g.K + MBK - 1) / MBK : g.K / MBK;     // conv / lstm: every tile through a select loader
     auto swrite = [&](int b) {
         float *As = lds + b * BUF_FLOATS, *Ws = As + A_FLOATS;
@@ -615,6 +654,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     }
     }
     if (PP && !active) return;
+    tail_mfma();
 
     GSTAMP(1)
     if (LSTM) {

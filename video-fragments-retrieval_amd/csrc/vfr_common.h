@@ -27,6 +27,8 @@ int opt_lstm_xcd();
 int opt_gemm_small();
 int opt_lstm_tile();
 int opt_lstm_small4();
+int opt_lstm_persist();
+int device_cu_count();
 int opt_lstm_small();
 int opt_gemm_pp();
 int opt_mfma_min();
