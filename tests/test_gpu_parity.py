@@ -351,6 +351,28 @@ def test_vgg_conv_launch_forms_bit_exact(vfr, oracle, cfg, T):
     got = vfr.vgg_fc7(dev(frames), cfg, [dev(w) for w in cw], [dev(b) for b in cb],
                       (dev(fc6[0]), dev(fc6[1])), (dev(fc7[0]), dev(fc7[1])))
     assert same(got, oracle.vgg_fc7(frames, cw, cb, fc6, fc7, cfg))
+    # the max-pools above ran inside the preceding convolution's epilogue (EPI_POOL2: GEMM rows in pooling-window order);
+    # the same stack with the pools as their own kernels
+    try:
+        vfr.set_option("vgg_fuse_pool", 0)
+        vfr.set_option("vgg_direct1", 0)          # and the first convolution through the implicit-GEMM kernel instead of the direct one
+        unfused = vfr.vgg_fc7(dev(frames), cfg, [dev(w) for w in cw], [dev(b) for b in cb],
+                              (dev(fc6[0]), dev(fc6[1])), (dev(fc7[0]), dev(fc7[1])))
+    finally:
+        vfr.set_option("vgg_fuse_pool", 1)
+        vfr.set_option("vgg_direct1", 1)
+    assert torch.equal(got.view(torch.int32), unfused.view(torch.int32))
+
+
+def test_vgg_first_conv_direct_kernel_ragged(vfr, oracle):
+    """The direct first-convolution kernel's 16-channel rounds (LDS-transposed stores) on a pixel count that is no multiple of
+    a wave, a pool on an odd height behind it (not fusable) and fused ones elsewhere: == oracle."""
+    cfg = [48, 8, "M", 8, "M", 8, "M"]
+    frames = synth.frames_u8(3, 36, 28, seed=9)
+    cw, cb, fc6, fc7 = synth.vgg_weights(cfg, (36, 28), 64, seed=9)
+    got = vfr.vgg_fc7(dev(frames), cfg, [dev(w) for w in cw], [dev(b) for b in cb],
+                      (dev(fc6[0]), dev(fc6[1])), (dev(fc7[0]), dev(fc7[1])))
+    assert same(got, oracle.vgg_fc7(frames, cw, cb, fc6, fc7, cfg))
 
 
 # ---------------------------------------------------------------------------------------------

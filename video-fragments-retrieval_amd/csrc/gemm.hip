@@ -345,6 +345,29 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // (from the tile's first pixel, biased by one image row + 1 so that it stays non-negative under every displacement) remain
     unsigned ctap[NA], coffb[NA];
     const int cbias = CFAST ? (g.conv_w + 1) * g.conv_cin : 0;          // floats
+    // GEMM row -> output pixel (n, y, x) and its linear NHWC pixel index.  Plain order: row = pixel index.  EPI_POOL2: the rows
+    // of a 2x2 pooling window are adjacent (row = window * 4 + (y & 1) * 2 + (x & 1), windows in pooled-NHWC order), so a lane's
+    // accumulator quad is one window.  The linear index grows with the row in both orders (window starts ascending).
+    const bool cpool = CONV && (g.epi & EPI_POOL2) != 0;
+    auto conv_pixel = [&](int64_t pc, int &n_, int &y_, int &x_) -> int64_t {
+        const int hw = g.conv_h * g.conv_w;
+        if (cpool) {
+            const int64_t q = pc >> 2;
+            const int sub = (int)(pc & 3), hw4 = hw >> 2, w2 = g.conv_w >> 1;
+            n_ = (int)(q / hw4);
+            const int rem = (int)(q - (int64_t)n_ * hw4), y2 = rem / w2;
+            y_ = 2 * y2 + (sub >> 1);
+            x_ = 2 * (rem - y2 * w2) + (sub & 1);
+        } else {
+            n_ = (int)(pc / hw);
+            const int rem = (int)(pc - (int64_t)n_ * hw);
+            y_ = rem / g.conv_w;
+            x_ = rem - y_ * g.conv_w;
+        }
+        return ((int64_t)n_ * g.conv_h + y_) * g.conv_w + x_;
+    };
+    int64_t clin0 = m0;                                                 // linear pixel index of the tile's first row
+    if (CONV && cpool) { int n0_, y0_, x0_; clin0 = conv_pixel(m0 < g.M ? m0 : 0, n0_, y0_, x0_); }
     if (CONV) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -352,11 +375,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             const int64_t p = m0 + row;
             crow_ok[i] = p < g.M;
             const int64_t pc = crow_ok[i] ? p : 0;
-            const int hw = g.conv_h * g.conv_w;
-            cn[i] = (int)(pc / hw);
-            const int rem = (int)(pc - (int64_t)cn[i] * hw);
-            coy[i] = rem / g.conv_w;
-            cox[i] = rem - coy[i] * g.conv_w;
+            const int64_t plin = conv_pixel(pc, cn[i], coy[i], cox[i]);
             if (CFAST) {
                 unsigned mask = 0;
 #pragma unroll
@@ -365,7 +384,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                     if (crow_ok[i] && iy >= 0 && iy < g.conv_h && ix >= 0 && ix < g.conv_w) mask |= 1u << t;
                 }
                 ctap[i] = mask;
-                coffb[i] = (unsigned)(((crow_ok[i] ? (int64_t)row : 0) * g.conv_cin + (f & 7) * 4 + cbias) * 4);
+                coffb[i] = (unsigned)(((crow_ok[i] ? plin - clin0 : 0) * g.conv_cin + (f & 7) * 4 + cbias) * 4);
             }
         }
     }
@@ -376,7 +395,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         const int dpix = (ky - 1) * g.conv_w + (kx - 1);
         const unsigned dbytes = (unsigned)(dpix * g.conv_cin * 4), tbit = 1u << tap;
         // (m0 + dpix) * C_in + ci0 - bias may lie before the tensor: only ever dereferenced with an in-image offset added
-        const char *ba = reinterpret_cast<const char *>(g.A + ((m0 + dpix) * g.conv_cin + ci0 - cbias));
+        const char *ba = reinterpret_cast<const char *>(g.A + ((clin0 + dpix) * g.conv_cin + ci0 - cbias));
         const char *bw = reinterpret_cast<const char *>(g.W + (int64_t)n0 * g.ldw + k0);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -712,6 +731,24 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #endif
         return;
     }
+    if (CONV && (g.epi & EPI_POOL2)) {
+        // 2x2 max-pool in place of the store of four rows: the quad (rows 4*lq .. 4*lq + 3 of a 16-row block) is one window
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) {
+                const int col = n0 + wn * 64 + tj * 16 + l15;
+                const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq;
+                if (col >= g.N || row >= g.M) continue;
+                const float badd = (g.epi & EPI_BIAS) ? g.bias[col] : 0.0f;
+                float v = acc[ti][tj][0] + badd;
+#pragma unroll
+                for (int r = 1; r < 4; ++r) { const float x = acc[ti][tj][r] + badd; v = x > v ? x : v; }
+                if (g.epi & EPI_RELU) v = v > 0.0f ? v : 0.0f;
+                g.out[(row >> 2) * g.ldo + col] = v;
+            }
+        return;
+    }
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -955,7 +992,11 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
                         ((((uintptr_t)g.A) | ((uintptr_t)g.W)) & 15) == 0,
                     VFR_EINVAL, "gemm_nt(conv): needs Cin %% 4 == 0, K = 9*Cin and 16-byte aligned operands");
         // C_in a multiple of 32 (every VGG layer but the first): the loader with scalar tap arithmetic
-        const bool cf = (g.conv_cin % MBK) == 0 && (int64_t)(g.conv_w + 1 + MBM + 2 * g.conv_w + 2) * g.conv_cin * 4 < (1ll << 31);
+        VFR_REQUIRE(!(g.epi & EPI_POOL2) || ((g.conv_h | g.conv_w) & 1) == 0, VFR_EINVAL, "gemm_nt(conv): the fused 2x2 pool needs even height and width");
+        VFR_REQUIRE(!(g.epi & EPI_POOL2) || !(g.epi & (EPI_RES | EPI_VIS | EPI_BIAS2)), VFR_EINVAL, "gemm_nt(conv): fused pool with bias / ReLU only");
+        // (the offsets of a tile's rows from its first pixel: 128 consecutive pixels, or with the fused pool 32 windows that may
+        // wrap over window rows -- under 2 * 128 + 4 * w pixels)
+        const bool cf = (g.conv_cin % MBK) == 0 && (int64_t)(g.conv_w + 1 + 2 * MBM + 4 * g.conv_w + 2 * g.conv_w + 2) * g.conv_cin * 4 < (1ll << 31);
 #define VFR_CONV(MI_, NARROW_, GRID_, ARGS_)                                                                            \
         do {                                                                                                            \
             if (cf) hipLaunchKernelGGL((conv3x3_nhwc_mfma<MI_, NARROW_, true>), GRID_, dim3(256), 0, st, ARGS_);         \

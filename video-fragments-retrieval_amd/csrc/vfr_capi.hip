@@ -24,6 +24,8 @@ static std::atomic<int> g_opt_gemm_pp{0};          // 1: ping-pong schedule (512
 static std::atomic<int> g_opt_mfma_min{128};        // banks of fewer videos go to the exact scorer (the pre-filter's fixed launches cost more); tests set 0
 static std::atomic<int> g_opt_lstm_small{2};       // batches of up to this many queries (<= 4) take the vector-chain LSTM step (measured: 17 / 25 / 38 us per step at 1 / 2 / 4 queries against 34 for the MFMA tiles); 0: always the tiles
 static std::atomic<int> g_opt_lstm_persist{1};     // 1: one or two queries run the whole sequence in ONE launch with the weights resident in LDS (lstm_seq_small_kernel); 0: one launch per step
+static std::atomic<int> g_opt_vgg_fuse_pool{1};    // 1: a 2x2 max-pool behind a VGG convolution runs in that convolution's epilogue (EPI_POOL2); 0: its own kernel (cross-check)
+static std::atomic<int> g_opt_vgg_direct1{1};      // 1: the first VGG convolution (3 channels, K = 36) as the direct kernel; 0: the implicit-GEMM MFMA kernel (cross-check)
 static std::atomic<int> g_opt_lstm_small4{1};      // 1: a single query of the model's shape takes the four-wave vector-chain step (weights streamed by three loader waves); 0: the one-wave step (cross-check)
 static std::atomic<int> g_opt_lstm_tile{0};        // 0: by grid size, 1: 64-row tiles, 2: 128-row tiles (fused LSTM step)
 
@@ -31,7 +33,7 @@ struct Opt { const char *name; std::atomic<int> *v; };
 static const Opt g_opts[] = {
     {"gemm", &g_opt_gemm}, {"profile", &g_opt_profile}, {"score_fast", &g_opt_score_fast}, {"score_split", &g_opt_score_split},
     {"score_pre_b", &g_opt_score_pre_b}, {"score_smallq", &g_opt_score_smallq}, {"score_tasks", &g_opt_score_tasks}, {"lstm_skip0", &g_opt_lstm_skip0},
-    {"lstm_xcd", &g_opt_lstm_xcd}, {"gemm_small", &g_opt_gemm_small}, {"lstm_tile", &g_opt_lstm_tile}, {"lstm_small4", &g_opt_lstm_small4}, {"lstm_persist", &g_opt_lstm_persist}, {"gemm_pp", &g_opt_gemm_pp}, {"score_mfma_min", &g_opt_mfma_min}, {"lstm_small", &g_opt_lstm_small},
+    {"lstm_xcd", &g_opt_lstm_xcd}, {"gemm_small", &g_opt_gemm_small}, {"lstm_tile", &g_opt_lstm_tile}, {"lstm_small4", &g_opt_lstm_small4}, {"lstm_persist", &g_opt_lstm_persist}, {"vgg_fuse_pool", &g_opt_vgg_fuse_pool}, {"vgg_direct1", &g_opt_vgg_direct1}, {"gemm_pp", &g_opt_gemm_pp}, {"score_mfma_min", &g_opt_mfma_min}, {"lstm_small", &g_opt_lstm_small},
 };
 
 struct ProfPair { int site; hipEvent_t a, b; };
@@ -89,6 +91,8 @@ int opt_gemm_small() { return g_opt_gemm_small; }
 int opt_lstm_tile() { return g_opt_lstm_tile; }
 int opt_lstm_small4() { return g_opt_lstm_small4; }
 int opt_lstm_persist() { return g_opt_lstm_persist; }
+int opt_vgg_fuse_pool() { return g_opt_vgg_fuse_pool; }
+int opt_vgg_direct1() { return g_opt_vgg_direct1; }
 int device_cu_count()
 {
     static std::atomic<int> cus{-1};

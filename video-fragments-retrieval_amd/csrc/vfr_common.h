@@ -28,6 +28,8 @@ int opt_gemm_small();
 int opt_lstm_tile();
 int opt_lstm_small4();
 int opt_lstm_persist();
+int opt_vgg_fuse_pool();
+int opt_vgg_direct1();
 int device_cu_count();
 int opt_lstm_small();
 int opt_gemm_pp();
@@ -78,6 +80,10 @@ enum : int {
     EPI_RELU = 4,      // max(x, 0) last
     EPI_VIS = 8,       // clip-encoder hidden layer: x = ((chain + vis_cx[vis_row[m]][n]) + fma(te1, vis_w1[n], fma(te0, vis_w0[n], 0))) + bias[n]
     EPI_RES = 16,      // + res[m][n] after the bias, before the ReLU (a residual block's identity branch)
+    EPI_POOL2 = 32,    // implicit-GEMM convolution only: 2x2 / stride-2 max-pool of the (bias, ReLU) output fused into the epilogue.
+                       // GEMM row m = ((n*(h/2) + y/2)*(w/2) + x/2)*4 + (y&1)*2 + (x&1): the four rows a lane's accumulator
+                       // register quad holds are one pooling window, so the max needs no exchange; out is the POOLED NHWC
+                       // tensor [M/4, N].  Needs even conv_h / conv_w.
 };
 struct GemmArgs {
     const float *A; int64_t lda;

@@ -131,6 +131,83 @@ __global__ __launch_bounds__(256) void conv_weight_repack_kernel(const float *__
     wr[i] = ci < Cin ? w[((int64_t)co * Cin + ci) * 9 + tap] : 0.0f;
 }
 
+// First convolution of the stack (3 input channels travelling padded to 4): K = 36 is a single K-tile of the MFMA kernel --
+// all prologue and 1.9 GB of output per 150-frame video, 23 TF.  Direct form: thread = output pixel, its 3x3x3 neighbourhood
+// in 27 registers, the weights wave-uniform (scalar loads), one 27-term chain per output channel in the GEMM's order
+// (k = tap * 4 + ci ascending; the padded channel's products are +0 onto a chain that is never -0: skipped), + bias, ReLU.
+// Weights for it: w [Cout, 3, 3, 3] -> wq [Cout / 4][27][4], the four output channels of a quad adjacent per k = tap * 3 + ci
+// (one scalar 16-byte load feeds four chains).
+__global__ __launch_bounds__(256) void conv_c4_weight_quad_kernel(const float *__restrict__ w, int Cout, float *__restrict__ wq)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cout * 27) return;
+    const int j = i & 3, k = (i >> 2) % 27, q = i / 108, tap = k / 3, ci = k - 3 * tap, co = 4 * q + j;
+    wq[i] = w[(co * 3 + ci) * 9 + tap];
+}
+// T16: Cout a multiple of 16 -- 16 channels per round, handed through a wave-private LDS tile so that a store instruction writes
+// 16 pixels x 64 contiguous bytes (4 lanes per pixel) instead of 64 pixels x 16 bytes a 256-byte stride apart (the output is
+// 1.9 GB per 150-frame video: partial-line writes were the whole cost of the first version).
+template <bool T16>
+__global__ __launch_bounds__(256) void conv3x3_c4_direct_kernel(const float4 *__restrict__ x, int64_t pixels, int H, int W,
+                                                                const float4 *__restrict__ wq, const float *__restrict__ b, int Cout,
+                                                                float *__restrict__ y)
+{
+    __shared__ __attribute__((aligned(16))) float tile_s[T16 ? 4 * 64 * 16 : 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pc = p < pixels ? p : pixels - 1;                     // (rows past the end: recomputed, never stored)
+    const int hw = H * W;
+    const int64_t n = pc / hw;
+    const int rem = (int)(pc - n * hw), oy = rem / W, ox = rem - oy * W;
+    float xin[27];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float4 v = x[ok ? (n * H + iy) * W + ix : pc];
+        xin[tap * 3 + 0] = ok ? v.x : 0.0f; xin[tap * 3 + 1] = ok ? v.y : 0.0f; xin[tap * 3 + 2] = ok ? v.z : 0.0f;
+    }
+    auto quad = [&](int co) -> float4 {
+        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float4 *wk = wq + (co >> 2) * 27;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const float4 wv = wk[k];
+            a[0] = __builtin_fmaf(xin[k], wv.x, a[0]); a[1] = __builtin_fmaf(xin[k], wv.y, a[1]);
+            a[2] = __builtin_fmaf(xin[k], wv.z, a[2]); a[3] = __builtin_fmaf(xin[k], wv.w, a[3]);
+        }
+        float4 o;
+        o.x = a[0] + b[co]; o.y = a[1] + b[co + 1]; o.z = a[2] + b[co + 2]; o.w = a[3] + b[co + 3];
+        o.x = o.x > 0.0f ? o.x : 0.0f; o.y = o.y > 0.0f ? o.y : 0.0f; o.z = o.z > 0.0f ? o.z : 0.0f; o.w = o.w > 0.0f ? o.w : 0.0f;
+        return o;
+    };
+    if constexpr (T16) {
+        float *tile = tile_s + wv * 64 * 16;
+        const int64_t pw = (int64_t)blockIdx.x * 256 + wv * 64;         // the wave's first pixel
+        for (int co = 0; co < Cout; co += 16) {
+            float4 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = quad(co + 4 * j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(tile + lane * 16 + 4 * j) = o[j];
+            __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0): the tile is the wave's own
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pl = (lane >> 2) + 16 * j;
+                const float4 v = *reinterpret_cast<const float4 *>(tile + pl * 16 + 4 * (lane & 3));
+                if (pw + pl < pixels) *reinterpret_cast<float4 *>(y + (pw + pl) * Cout + co + 4 * (lane & 3)) = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        if (p >= pixels) return;
+        float4 *yo = reinterpret_cast<float4 *>(y + p * Cout);
+        for (int co = 0; co < Cout; co += 4) yo[co >> 2] = quad(co);
+    }
+}
+
 __global__ __launch_bounds__(256) void maxpool2_nhwc_kernel(const float *__restrict__ x, int64_t B, int H, int W, int C,
                                                             float *__restrict__ y)
 {
@@ -303,6 +380,9 @@ int vfr_vgg_fc7_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *
     float *wr_base = reinterpret_cast<float *>(base + 2 * act + pooled_b + h6_b);
     const int K6 = p.c_last * 49;
 
+    // the stack's first convolution (3 channels, K = 36) takes the direct kernel unless a pool is fused behind it
+    const bool direct1 = vfr::opt_vgg_direct1() && cfg_host[0] > 0 && (cfg_host[0] % 4) == 0 &&
+                         !(vfr::opt_vgg_fuse_pool() && ncfg > 1 && cfg_host[1] <= 0 && ((H | W) & 1) == 0);
     // repack every conv weight once per call: [Cout,Cin,3,3] -> [Cout, 9*Cinp] tap-major (the chain order)
     {
         vfr::ProfScope prof(vfr::SITE_REPACK, st);
@@ -312,6 +392,10 @@ int vfr_vgg_fc7_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *
             if (cfg_host[i] <= 0) continue;
             const int cinp = cin < 4 ? 4 : cin, cout = cfg_host[i];
             const int64_t n = (int64_t)cout * 9 * cinp;
+            if (conv == 0 && direct1)             // (the direct kernel's quad layout: 27 * Cout floats in the same slot)
+                hipLaunchKernelGGL(vfr::conv_c4_weight_quad_kernel, dim3((unsigned)vfr::cdiv((int64_t)cout * 27, 256)), dim3(256), 0, st,
+                                   conv_w_host[conv], cout, wr);
+            else
             hipLaunchKernelGGL(vfr::conv_weight_repack_kernel, dim3((unsigned)vfr::cdiv(n, 256)), dim3(256), 0, st,
                                conv_w_host[conv], cout, cin, cinp, wr);
             wr += vfr::align_up((size_t)n, 64);
@@ -340,10 +424,26 @@ int vfr_vgg_fc7_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *
                 g.A = cur; g.W = wr; g.ldw = 9 * c; g.out = nxt; g.ldo = cout; g.M = (int64_t)bt * h * w; g.N = cout;
                 g.K = 9 * c; g.bias = conv_b_host[conv]; g.epi = vfr::EPI_BIAS | vfr::EPI_RELU; g.site = vfr::SITE_CONV;
                 g.conv_h = h; g.conv_w = w; g.conv_cin = c;
+                // a max-pool right behind this convolution rides in its epilogue (the window is a lane's accumulator quad):
+                // the full-resolution activation is never written, the pool kernel never runs
+                const bool pool = vfr::opt_vgg_fuse_pool() && i + 1 < ncfg && cfg_host[i + 1] <= 0 && ((h | w) & 1) == 0;
+                if (pool) g.epi |= vfr::EPI_POOL2;
+                if (conv == 0 && direct1) {
+                    vfr::ProfScope prof(vfr::SITE_CONV, st);
+                    if (cout % 16 == 0)
+                        hipLaunchKernelGGL(vfr::conv3x3_c4_direct_kernel<true>, dim3((unsigned)vfr::cdiv(g.M, 256)), dim3(256), 0, st,
+                                           reinterpret_cast<const float4 *>(cur), g.M, h, w, reinterpret_cast<const float4 *>(wr),
+                                           conv_b_host[conv], cout, nxt);
+                    else
+                        hipLaunchKernelGGL(vfr::conv3x3_c4_direct_kernel<false>, dim3((unsigned)vfr::cdiv(g.M, 256)), dim3(256), 0, st,
+                                           reinterpret_cast<const float4 *>(cur), g.M, h, w, reinterpret_cast<const float4 *>(wr),
+                                           conv_b_host[conv], cout, nxt);
+                } else
                 if (int rc = vfr::gemm_nt(g, st)) return rc;
                 wr += vfr::align_up((size_t)cout * 9 * c, 64);
                 c = cout;
                 ++conv;
+                if (pool) { h /= 2; w /= 2; ++i; }
             } else {
                 vfr::ProfScope prof(vfr::SITE_POOL2D, st);
                 const int64_t n = (int64_t)bt * (h / 2) * (w / 2) * (c / 4);
