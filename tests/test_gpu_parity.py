@@ -497,7 +497,8 @@ def test_file_dataset_pools_on_gpu_and_evaluates(vfr, oracle, golden, mode, tmp_
 @pytest.mark.gpu
 @pytest.mark.parametrize("nq", [1, 2, 3, 5, 8])
 def test_few_queries_scoring_path(vfr, nq):
-    """1-8 queries (a serving request) are scored with lanes = clips / videos and a selection tree over the key array
+    """1-8 queries (a serving request) are scored with lanes = clips / videos; the top-k comes from the videos whose smallest
+    clip distance can still reach it (`score_smallq_select`; off: a selection tree over the key array)
     (`score_smallq`): top-k lists and rank counts bit-identical to the fused kernels (option off) and to dense + stable sort;
     ragged clip counts, an empty video, duplicated videos (exact ties), k = 0 / 1 / 100 / more than there are moments, 1-4 rank keys."""
     rs = np.random.RandomState(40 + nq)
@@ -523,9 +524,15 @@ def test_few_queries_scoring_path(vfr, nq):
             try:
                 vfr.set_option("score_smallq", 0)
                 d2, i2, c2 = vfr.score_topk(Q, bank, k, rd, ri, mode="mfma")
+                vfr.set_option("score_smallq", 8)
+                vfr.set_option("score_smallq_select", 0)       # the key array + selection tree instead of the video selection
+                d3, i3, c3 = vfr.score_topk(Q, bank, k, rd, ri, mode="mfma")
             finally:
                 vfr.set_option("score_smallq", 8)
-            assert c.tolist() == [[p] * nq for p in pos] and torch.equal(c, c2)
+                vfr.set_option("score_smallq_select", 1)
+            assert c.tolist() == [[p] * nq for p in pos] and torch.equal(c, c2) and torch.equal(c, c3)
+            if k:
+                assert torch.equal(i, i3) and torch.equal(d, d3)
             if k:
                 kk = min(k, total)
                 assert torch.equal(i[:, :kk], order[:, :kk]) and torch.equal(d[:, :kk], dense.gather(1, order[:, :kk]))

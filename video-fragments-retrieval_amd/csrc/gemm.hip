@@ -351,6 +351,19 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     const bool cpool = CONV && (g.epi & EPI_POOL2) != 0;
     auto conv_pixel = [&](int64_t pc, int &n_, int &y_, int &x_) -> int64_t {
         const int hw = g.conv_h * g.conv_w;
+        if (g.M < (1ll << 31)) {
+            // (the usual case in 32-bit arithmetic: a 64-bit division is ~100 instructions, and a K = 576 layer's tile is short)
+            const unsigned pu = (unsigned)pc, w_ = (unsigned)g.conv_w;
+            if (cpool) {
+                const unsigned q = pu >> 2, sub = pu & 3u, hw4 = (unsigned)hw >> 2, w2 = w_ >> 1;
+                const unsigned nn = q / hw4, rem = q - nn * hw4, y2 = rem / w2;
+                n_ = (int)nn; y_ = (int)(2 * y2 + (sub >> 1)); x_ = (int)(2 * (rem - y2 * w2) + (sub & 1u));
+            } else {
+                const unsigned nn = pu / (unsigned)hw, rem = pu - nn * (unsigned)hw, yy = rem / w_;
+                n_ = (int)nn; y_ = (int)yy; x_ = (int)(rem - yy * w_);
+            }
+            return ((int64_t)n_ * g.conv_h + y_) * g.conv_w + x_;
+        }
         if (cpool) {
             const int64_t q = pc >> 2;
             const int sub = (int)(pc & 3), hw4 = hw >> 2, w2 = g.conv_w >> 1;

@@ -1554,7 +1554,7 @@ __global__ __launch_bounds__(256) void smallq_moments_kernel(const float *__rest
                                                              const int64_t *__restrict__ mom_off, int Nv, int total_clips, int64_t id_base,
                                                              unsigned long long *__restrict__ keys, int64_t Mpad, int num_rank,
                                                              const float *__restrict__ rank_dist, const int64_t *__restrict__ rank_idx,
-                                                             int64_t *__restrict__ count_lt)
+                                                             int64_t *__restrict__ count_lt, float *__restrict__ dmin)
 {
     __shared__ unsigned long long stage[SQ_VIDEOS * SQ_MOM];
     __shared__ float ds[SQ_VIDEOS][SMALLQ_CLIPS_MAX + 3];
@@ -1570,7 +1570,13 @@ __global__ __launch_bounds__(256) void smallq_moments_kernel(const float *__rest
     int n = 0, c0 = 0;
     int64_t m0 = 0;
     if (v < Nv) { c0 = clip_off[v]; n = clip_off[v + 1] - c0; m0 = mom_off[v]; }
-    for (int c = sl; c < n; c += 16) ds[vl][c] = dist[(int64_t)q * total_clips + c0 + c];
+    float dm = __builtin_inff();
+    for (int c = sl; c < n; c += 16) { const float dv = dist[(int64_t)q * total_clips + c0 + c]; ds[vl][c] = dv; dm = dv < dm ? dv : dm; }
+    if (dmin) {           // the video's smallest clip distance = the score of its best one-clip moment (top-k selection below)
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { const float t = __shfl_xor(dm, o, 64); dm = t < dm ? t : dm; }
+        if (sl == 0 && v < Nv) dmin[(int64_t)q * Nv + v] = dm;
+    }
     __syncthreads();
     for (int s = sl; s < n; s += 16) {
         float sum = 0.0f;
@@ -1683,8 +1689,172 @@ __global__ __launch_bounds__(256) void topk_tree_kernel(const unsigned long long
     }
 }
 
+// Top-k of a handful of queries WITHOUT the key array and the selection tree (three latency-bound levels: 0.09 ms at one
+// query).  Every moment's score is a mean of its video's clip distances, so score >= dmin_v * (1 - 22 u) (dmin_v = the
+// video's smallest clip distance; each rounding is monotone), and dmin_v itself is the score of a one-clip moment.  Hence any
+// thr that is >= the k-th smallest dmin over the videos bounds the k-th best moment, and only videos with
+// dmin_v <= thr * (1 + 32 u) can hold a moment of the top-k.  One 1024-thread workgroup per query:
+//   A  thr: min / max of the dmin row, a 2048-bin histogram over [min, max], the first bin b* at which the running count
+//      reaches k; thr = the largest dmin in bins <= b* (>= k videos lie at or below it).  Nv <= k: thr = +inf (everything);
+//   B  the videos passing the margin test are listed in LDS (4096 at a time);
+//   C  thread = (listed video, start clip): the canonical sums and IEEE quotients of smallq_moments_kernel, keys <= (thr, max id)
+//      appended to the query's candidate run in global memory (the slot from an LDS counter: one workgroup owns the query);
+//   D  wave 0 runs the pool selection of the merge kernels over the candidates (typically a few hundred) and writes the rows.
+// Exact: the candidates are a superset of the top-k with the dense kernel's keys.
+constexpr int SQS_BINS = 2048, SQS_LIST = 4096, SQS_THREADS = 1024;
+template <int KPL>
+__global__ __launch_bounds__(SQS_THREADS) void smallq_select_kernel(const float *__restrict__ dist, const float *__restrict__ dmin,
+                                                                    const int32_t *__restrict__ clip_off, const int64_t *__restrict__ mom_off,
+                                                                    int Nv, int total_clips, int64_t id_base, int k,
+                                                                    unsigned long long *__restrict__ cand, int64_t cand_stride,
+                                                                    float *__restrict__ out_dist, int64_t *__restrict__ out_idx)
+{
+    constexpr int CAP = KPL * 64;
+    __shared__ int hist[SQS_BINS];
+    __shared__ int vlist[SQS_LIST];
+    __shared__ float redf[2][SQS_THREADS / 64];
+    __shared__ int redi[SQS_THREADS / 64];
+    __shared__ int s_bstar, s_nlist, s_ncand;
+    __shared__ unsigned long long pool[CAP];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float *dq = dmin + (int64_t)q * Nv;
+    unsigned long long *cq = cand + (int64_t)q * cand_stride;
+    // ---- A: threshold ----
+    float mn = __builtin_inff(), mx = 0.0f;
+    for (int v = tid; v < Nv; v += SQS_THREADS) { const float x = dq[v]; mn = x < mn ? x : mn; mx = (x > mx && x < __builtin_inff()) ? x : mx; }   // (a video without clips: +inf)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64); mn = a < mn ? a : mn; mx = b > mx ? b : mx; }
+    if (lane == 0) { redf[0][wv] = mn; redf[1][wv] = mx; }
+    for (int i = tid; i < SQS_BINS; i += SQS_THREADS) hist[i] = 0;
+    if (tid == 0) { s_nlist = 0; s_ncand = 0; s_bstar = SQS_BINS - 1; }
+    __syncthreads();
+    mn = redf[0][0]; mx = redf[1][0];
+#pragma unroll
+    for (int i = 1; i < SQS_THREADS / 64; ++i) { mn = redf[0][i] < mn ? redf[0][i] : mn; mx = redf[1][i] > mx ? redf[1][i] : mx; }
+    const float scale = mx > mn ? (float)(SQS_BINS - 1) / (mx - mn) : 0.0f;
+    auto bin_of = [&](float x) {
+        if (!(x < __builtin_inff())) return SQS_BINS - 1;
+        const int b = (int)((x - mn) * scale);
+        return b < 0 ? 0 : (b > SQS_BINS - 1 ? SQS_BINS - 1 : b);
+    };
+    float thr = __builtin_inff();
+    if (Nv > k) {
+        for (int v = tid; v < Nv; v += SQS_THREADS) atomicAdd(&hist[bin_of(dq[v])], 1);
+        __syncthreads();
+        // running count over the bins: thread t owns bins 2t, 2t + 1
+        const int h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+        int part = h0 + h1, incl = part;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) redi[wv] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int i = 0; i < wv; ++i) before += redi[i];
+        const int excl = before + incl - part;                              // videos in bins < 2t
+        if (excl < k && excl + h0 >= k) s_bstar = 2 * tid;
+        else if (excl + h0 < k && excl + part >= k) s_bstar = 2 * tid + 1;
+        __syncthreads();
+        const int bstar = s_bstar;
+        float tm = 0.0f;
+        for (int v = tid; v < Nv; v += SQS_THREADS) { const float x = dq[v]; if (bin_of(x) <= bstar) tm = x > tm ? x : tm; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const float a = __shfl_xor(tm, o, 64); tm = a > tm ? a : tm; }
+        if (lane == 0) redf[0][wv] = tm;
+        __syncthreads();
+        tm = redf[0][0];
+#pragma unroll
+        for (int i = 1; i < SQS_THREADS / 64; ++i) tm = redf[0][i] > tm ? redf[0][i] : tm;
+        thr = tm;
+    }
+    const unsigned long long thrkey = thr < __builtin_inff() ? (((unsigned long long)__float_as_uint(thr) << 32) | 0xFFFFFFFFull) : KEY_MAX;
+    const float vthr = thr < __builtin_inff() ? thr * (1.0f + 32.0f * 5.9604645e-8f) : thr;
+    // ---- B + C: listed videos, SQS_LIST at a time ----
+    for (int vbase = 0; vbase < Nv; ) {
+        __syncthreads();
+        if (tid == 0) s_nlist = 0;
+        __syncthreads();
+        // fill the list from vbase on; stop at the chunk of SQS_THREADS videos that would overflow it
+        int vend = vbase;
+        while (vend < Nv) {
+            const int v = vend + tid;
+            const bool sel = v < Nv && dq[v] <= vthr;
+            if (sel) { const int slot = atomicAdd(&s_nlist, 1); if (slot < SQS_LIST) vlist[slot] = v; }
+            vend += SQS_THREADS;
+            __syncthreads();
+            if (s_nlist + SQS_THREADS > SQS_LIST) break;                     // uniform: the next chunk might not fit
+            __syncthreads();
+        }
+        __syncthreads();
+        const int nlist = s_nlist < SQS_LIST ? s_nlist : SQS_LIST;          // (never exceeds: checked before every chunk)
+        for (int it = tid; it < nlist * SMALLQ_CLIPS_MAX; it += SQS_THREADS) {
+            const int v = vlist[it / SMALLQ_CLIPS_MAX], s0 = it % SMALLQ_CLIPS_MAX;
+            const int c0 = clip_off[v], n = clip_off[v + 1] - c0;
+            if (s0 >= n) continue;
+            const int64_t m0 = mom_off[v];
+            const float *dv = dist + (int64_t)q * total_clips + c0;
+            float sum = 0.0f;
+            for (int e = s0; e < n; ++e) {
+                const float de = dv[e];
+                sum = e == s0 ? de : sum + de;
+                const float sc = sum / (float)(e - s0 + 1);
+                const unsigned long long key = make_key(sc, (unsigned)(id_base + m0 + moment_index(n, s0, e)));
+                if (key <= thrkey) cq[atomicAdd(&s_ncand, 1)] = key;
+            }
+        }
+        vbase = vend < Nv ? vend : Nv;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (wv != 0) return;
+    // ---- D: wave 0 selects the k best of the candidates ----
+    const int64_t total = s_ncand;
+    unsigned long long key[KPL];
+    unsigned long long pthr = KEY_MAX;
+    int fill = 0;
+    auto lds_sync = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); };
+    auto sort_pool = [&](bool final_pass) {
+        lds_sync();
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) { const int e = i * 64 + lane; key[i] = e < fill ? pool[e] : KEY_MAX; }
+        wave_sort<KPL>(key, lane);
+        if (final_pass) return;
+        lds_sync();
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) { const int e = i * 64 + lane; if (e < k) pool[e] = key[i]; }
+        if (fill >= k) pthr = key_at<KPL>(key, k - 1);
+        fill = fill < k ? fill : k;
+    };
+    for (int64_t done = 0; done < total; done += CAP) {
+        unsigned long long x[KPL];
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const int64_t gi = done + i * 64 + lane;
+            const unsigned long long vv = cq[gi < total ? gi : total - 1];
+            x[i] = gi < total ? vv : KEY_MAX;
+        }
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            if (fill + 64 > CAP) sort_pool(false);
+            const bool pass = x[i] < pthr;
+            const unsigned long long m = __ballot(pass);
+            if (pass) pool[fill + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = x[i];
+            fill += __builtin_popcountll(m);
+        }
+    }
+    sort_pool(true);
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const int e = i * 64 + lane;
+        if (e < k) {
+            const bool ok = key[i] != KEY_MAX;
+            out_dist[(int64_t)q * k + e] = ok ? __uint_as_float((unsigned)(key[i] >> 32)) : __builtin_inff();
+            out_idx[(int64_t)q * k + e] = ok ? (int64_t)(key[i] & 0xffffffffull) : -1;
+        }
+    }
+}
+
 constexpr int SMALLQ_MAX = 8, SMALLQ_CLIPS = SMALLQ_CLIPS_MAX;
-struct SmallqWs { float *dist; unsigned long long *keys, *bufa, *bufb; int64_t Mpad, P0, P1; size_t total; };
+struct SmallqWs { float *dist; unsigned long long *keys, *bufa, *bufb; float *dmin; int64_t Mpad, P0, P1; size_t total; };
 constexpr int SQ_F1 = 20, SQ_F = 32;        // lists of k per first-level range; fan-in of the later levels
 static SmallqWs carve_smallq(void *base, int64_t Nq, int total_clips, int k)
 {
@@ -1700,6 +1870,7 @@ static SmallqWs carve_smallq(void *base, int64_t Nq, int total_clips, int k)
         w.keys = reinterpret_cast<unsigned long long *>(take((size_t)Nq * w.Mpad * 8));
         w.bufa = reinterpret_cast<unsigned long long *>(take((size_t)Nq * w.P1 * k * 8));
         w.bufb = reinterpret_cast<unsigned long long *>(take((size_t)Nq * cdiv(w.P1, SQ_F) * k * 8));
+        w.dmin = reinterpret_cast<float *>(take((size_t)Nq * total_clips * 4));           // (Nv <= total_clips)
     }
     w.total = off;
     return w;
@@ -2011,12 +2182,30 @@ static int run_smallq(const float *Q, int64_t Nq, const float *V, const int32_t 
         else if (Nq == 2) hipLaunchKernelGGL(smallq_dist_kernel<2>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
         else if (Nq <= 4) hipLaunchKernelGGL(smallq_dist_kernel<4>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
         else              hipLaunchKernelGGL(smallq_dist_kernel<8>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
+        // top-k by video selection (smallq_select_kernel) unless switched off: then the key array + selection tree
+        const bool select = k > 0 && opt_score_smallq_select();
         // unwritten key slots (the padding past the last moment) must read as empty: any value >= KEY_EMPTY does
-        if (k > 0 && hipMemsetAsync(w.keys, 0xFF, (size_t)Nq * w.Mpad * 8, st) != hipSuccess)
+        if (k > 0 && !select && hipMemsetAsync(w.keys, 0xFF, (size_t)Nq * w.Mpad * 8, st) != hipSuccess)
             return fail(VFR_EHIP, "vfr_score_topk_mfma: hipMemsetAsync failed");
-        hipLaunchKernelGGL(smallq_moments_kernel, dim3((unsigned)cdiv(Nv, SQ_VIDEOS), (unsigned)Nq), dim3(256), 0, st, w.dist, (int)Nq, clip_offsets,
-                           moment_offsets, Nv, total_clips, id_base, k > 0 ? w.keys : nullptr, w.Mpad, num_rank, rank_dist, rank_idx, count_lt);
+        if (k > 0 || num_rank > 0)
+            hipLaunchKernelGGL(smallq_moments_kernel, dim3((unsigned)cdiv(Nv, SQ_VIDEOS), (unsigned)Nq), dim3(256), 0, st, w.dist, (int)Nq, clip_offsets,
+                               moment_offsets, Nv, total_clips, id_base, (k > 0 && !select) ? w.keys : nullptr, w.Mpad, num_rank, rank_dist, rank_idx,
+                               count_lt, select ? w.dmin : nullptr);
         VFR_CHECK_LAUNCH("smallq kernels");
+    }
+    {
+        const bool select = k > 0 && opt_score_smallq_select();
+        if (select) {
+            ProfScope prof2(SITE_TOPK_MERGE, st);
+            if (kpl_for(k) == 4)
+                hipLaunchKernelGGL(smallq_select_kernel<4>, dim3((unsigned)Nq), dim3(SQS_THREADS), 0, st, w.dist, w.dmin, clip_offsets, moment_offsets,
+                                   Nv, total_clips, id_base, k, w.keys, w.Mpad, out_dist, out_idx);
+            else
+                hipLaunchKernelGGL(smallq_select_kernel<8>, dim3((unsigned)Nq), dim3(SQS_THREADS), 0, st, w.dist, w.dmin, clip_offsets, moment_offsets,
+                                   Nv, total_clips, id_base, k, w.keys, w.Mpad, out_dist, out_idx);
+            VFR_CHECK_LAUNCH("smallq_select_kernel");
+            return VFR_OK;
+        }
     }
     if (k == 0) return VFR_OK;
     // selection tree: ranges of SQ_F1 lists of k keys -> lists of k, then SQ_F lists at a time until one list per query is left

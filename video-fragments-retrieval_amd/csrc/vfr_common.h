@@ -21,6 +21,7 @@ int opt_score_fast();
 int opt_score_split();
 int opt_score_pre_b();
 int opt_score_smallq();
+int opt_score_smallq_select();
 int opt_score_tasks();
 int opt_lstm_skip0();
 int opt_lstm_xcd();
