@@ -160,6 +160,13 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
  * re-scored exactly, pairs the (video, group) bitmap can mark = Nq * Nv}.                                             */
 int vfr_score_topk_mfma_stats(const void *workspace, int64_t Nq, int Nv, int total_clips, int k, int64_t *stats_host,
                               vfr_stream_t stream);
+/* Device self-check of the arithmetic model the pre-filter's margins and the MFMA GEMMs' bit-exactness assume: a
+ * v_mfma_f32_16x16x4_f32 = four fp32 fmas, k ascending, on its accumulator (denormals kept).  A, B [16, K] device rows
+ * (K % 4 == 0; make them adversarial: wide exponent range, cancellation, denormals): C = A B^T by the matrix pipe against an
+ * explicit fmaf chain per element; *mismatches (device int) = elements whose bits differ -- 0 on a conforming device.
+ * reversed != 0 runs the reference chain k-descending (what a failing check looks like).  The Python layer runs it once per
+ * process before the first "mfma" / "bf16" scoring call and falls back to the exact kernels if it fails.          */
+int vfr_mfma_selfcheck(const float *A, const float *B, int K, int reversed, int *mismatches, vfr_stream_t stream);
 /* merge G per-shard top-k lists (after the RCCL all-gather): part_dist/part_idx
  * [G, Nq, k] -> out [Nq, k], same (distance, id) order.                                        */
 int vfr_topk_merge_f32(const float *part_dist, const int64_t *part_idx, int G, int64_t Nq, int k, float *out_dist,

@@ -541,6 +541,17 @@ def test_few_queries_scoring_path(vfr, nq):
 
 
 @pytest.mark.gpu
+def test_mfma_selfcheck_passes_and_can_fail(vfr):
+    """What the pre-filter's margins assume about the matrix pipe -- one v_mfma_f32_16x16x4_f32 = four fp32 fmas, k ascending,
+    denormals kept -- checked on THIS device against an explicit fmaf chain on adversarial rows (wide exponents, cancelling
+    neighbours, denormal operands): no element differs; against the k-descending chain many do (the check can fail).  The
+    scoring wrapper runs it once per process before the first "mfma" call and falls back to the exact kernels otherwise."""
+    assert vfr.mfma_selfcheck("cuda:0") == 0
+    assert vfr.mfma_selfcheck("cuda:0", reversed_reference=True) > 0
+    assert vfr._mfma_mode_ok(torch.device("cuda:0"))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["mfma", "bf16"])
 def test_prefilter_bank_products_reused_only_while_valid(vfr, mode):
     """Serving: query batches of different sizes against one resident bank and one workspace reuse the pre-filter's bank-side

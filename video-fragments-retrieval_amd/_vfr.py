@@ -13,6 +13,7 @@ import os
 import subprocess
 from pathlib import Path
 
+import numpy as np
 import torch
 
 _PKG = Path(__file__).resolve().parent
@@ -48,6 +49,7 @@ SIGNATURES = {
     "vfr_score_topk_mfma": (_i32, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i64, _i32, _vp, _vp, _i32,
                                    _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "vfr_score_topk_mfma_stats": (_i32, [_vp, _i64, _i32, _i32, _i32, ctypes.POINTER(ctypes.c_int64), _vp]),
+    "vfr_mfma_selfcheck": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "vfr_topk_merge_f32": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "vfr_topk_pack_keys": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "vfr_topk_merge_keys": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
@@ -317,6 +319,46 @@ MFMA_BANK_READY = 0x100                    # include/vfr.h VFR_MFMA_BANK_READY
 DEFAULT_SCORE_MODE = os.environ.get("VFR_SCORE_MODE", "mfma")
 
 
+_MFMA_CHECKED = {}                         # device index -> bool, one self-check per process and device
+
+
+def mfma_selfcheck(device=None, reversed_reference: bool = False) -> int:
+    """Number of elements (of 256) on which the matrix pipe's 16x16xK product differs from an explicit k-ascending fmaf chain
+    (include/vfr.h vfr_mfma_selfcheck) on adversarial rows: exponents spread over 2^-40 .. 2^40, every second product the
+    near-negation of its neighbour (cancellation), denormal operands.  0 on a conforming device.  SYNCHRONISES."""
+    device = torch.device(device if device is not None else "cuda")
+    rs = np.random.RandomState(2024)
+    K = 100
+
+    def rows():
+        m = rs.uniform(1.0, 2.0, (16, K)) * np.exp2(rs.randint(-40, 41, (16, K))) * rs.choice([-1.0, 1.0], (16, K))
+        m[:, 7::13] = 1e-41 * rs.randint(1, 9, m[:, 7::13].shape)          # denormal operands
+        return m.astype(np.float32)
+    A, B = rows(), rows()
+    A[:, 1::2] = -A[:, 0::2] * (1.0 + np.float32(2.0 ** -20))               # a_{2j+1} b_{2j+1} ~ -(a_2j b_2j): cancellation
+    B[:, 1::2] = B[:, 0::2]
+    a, b = torch.from_numpy(A).to(device), torch.from_numpy(B).to(device)
+    mis = torch.zeros(1, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        _check(lib().vfr_mfma_selfcheck(a.data_ptr(), b.data_ptr(), K, 1 if reversed_reference else 0, mis.data_ptr(), _stream()),
+               "vfr_mfma_selfcheck")
+    return int(mis.item())
+
+
+def _mfma_mode_ok(device) -> bool:
+    """The first "mfma" / "bf16" scoring call on a device runs the self-check; a device that fails it gets the exact kernels
+    (and a warning) for the rest of the process: the pre-filter's margins assume the checked arithmetic."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ok = _MFMA_CHECKED.get(idx)
+    if ok is None:
+        ok = _MFMA_CHECKED[idx] = mfma_selfcheck(device) == 0
+        if not ok:
+            import warnings
+            warnings.warn("vfr: the MFMA self-check failed on this device (v_mfma_f32_16x16x4_f32 is not a k-ascending fp32 fma "
+                          "chain here); scoring falls back to the exact kernels")
+    return ok
+
+
 def score_topk(Q: torch.Tensor, bank: VideoBank, k: int, rank_dist=None, rank_idx=None, count_lt=None,
                eps: float = 1e-6, workspace: torch.Tensor | None = None, thr_seed: torch.Tensor | None = None,
                mode: str | None = None):
@@ -329,6 +371,8 @@ def score_topk(Q: torch.Tensor, bank: VideoBank, k: int, rank_dist=None, rank_id
     if mode not in SCORE_MODES:
         raise RuntimeError(f"score_topk: unknown mode {mode!r}")
     Q = _dev(Q, torch.float32, "Q")
+    if mode != "exact" and not _mfma_mode_ok(Q.device):
+        mode = "exact"
     Nq = Q.shape[0]
     od = torch.empty((Nq, k), dtype=torch.float32, device=Q.device) if k > 0 else None
     oi = torch.empty((Nq, k), dtype=torch.int64, device=Q.device) if k > 0 else None

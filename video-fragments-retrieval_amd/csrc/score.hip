@@ -2169,6 +2169,32 @@ int vfr_gt_labels_u8(const int32_t *times, const int32_t *nannot, const int32_t 
 }  // extern "C"
 
 namespace vfr {
+// Device self-check of what the pre-filter's margins (and every MFMA GEMM's bit-exactness) rest on: one
+// v_mfma_f32_16x16x4_f32 is four fp32 fmas, k ascending, on top of its accumulator -- no wider intermediate, no other order,
+// denormal operands and results kept.  A 16 x 16 tile over K is computed by the matrix pipe and, element by element, as an
+// explicit fmaf chain on the vector ALU (`reversed`: the chain run k-descending -- what a failing check looks like); the
+// number of elements whose bits differ goes to *mismatches.
+__global__ __launch_bounds__(64) void mfma_selfcheck_kernel(const float *__restrict__ A, const float *__restrict__ B, int K, int reversed,
+                                                            int *__restrict__ mismatches)
+{
+    const int lane = threadIdx.x, l15 = lane & 15, lq = lane >> 4;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < K / 4; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[l15 * K + 4 * s + lq], B[l15 * K + 4 * s + lq], acc, 0, 0, 0);
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * lq + r, j = l15;
+        float ref = 0.0f;
+        for (int kk = 0; kk < K; ++kk) {
+            const int k = reversed ? K - 1 - kk : kk;
+            ref = __builtin_fmaf(A[i * K + k], B[j * K + k], ref);
+        }
+        bad += __float_as_uint(ref) != __float_as_uint(acc[r]) ? 1 : 0;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
 static int run_smallq(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets, const int64_t *moment_offsets, int Nv,
                       int total_clips, int D, float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
                       const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, void *workspace, vfr_stream_t stream)
@@ -2229,3 +2255,13 @@ static int run_smallq(const float *Q, int64_t Nq, const float *V, const int32_t 
     return VFR_OK;
 }
 }  // namespace vfr
+
+extern "C" int vfr_mfma_selfcheck(const float *A, const float *B, int K, int reversed, int *mismatches, vfr_stream_t stream)
+{
+    VFR_REQUIRE(A && B && mismatches && K > 0 && (K % 4) == 0, VFR_EINVAL, "vfr_mfma_selfcheck: bad argument (K a multiple of 4)");
+    hipStream_t st = vfr::as_stream(stream);
+    if (hipMemsetAsync(mismatches, 0, sizeof(int), st) != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_mfma_selfcheck: hipMemsetAsync failed");
+    hipLaunchKernelGGL(vfr::mfma_selfcheck_kernel, dim3(1), dim3(64), 0, st, A, B, K, reversed, mismatches);
+    VFR_CHECK_LAUNCH("mfma_selfcheck_kernel");
+    return VFR_OK;
+}
