@@ -289,7 +289,8 @@ def main():
             # a rank's two encoders are small enough from N = 4 on to leave CUs idle in their partial tile rounds: run them side
             # by side there (tools/rank_sim.py: -0.16 ms at 8, -0.09 at 4, +0.08 at 2); below they stay back to back (the per-kernel durations quoted in `roofline` are then undisturbed)
             emb, Q = engine.overlapped(dev, lambda: model.encode_clips(seg, ctx, clip_off),
-                                       lambda: engine.encode_queries(model, tokens, dev, ops, rank, world), enable=world >= 4)
+                                       lambda: engine.encode_queries(model, tokens, dev, ops, rank, world),
+                                       enable=world >= 4 or bool(os.environ.get("VFR_BENCH_OVERLAP")))   # (env: rehearsal switch)
             state["shard"], state["Q"] = make_shard(emb), Q
             return ranks_of(state["shard"], Q)
 

@@ -80,7 +80,12 @@ int vfr_linear_f32(const float *A, int64_t M, int K, const float *W, const float
  * tokens [B,T] int64; emb [vocab,E]; W_ih [4H,E], W_hh [4H,H], b_* [4H] (gate order i,f,g,o)
  * for the forward (_f) and reverse (_b) directions; Wfc [D,2H]; out [B,D].
  * The workspace also holds the per-vocabulary input-projection table (emb x W_ih^T, both directions) that the
- * recurrent steps start their gate chains from when vocab <= 32768 -- hence `vocab` in its size.  */
+ * recurrent steps start their gate chains from when vocab <= 32768 -- hence `vocab` in its size.
+ * B <= 2 at a shape whose 32-column weight slices fit a CU's LDS (E + H <= 1170, H <= 1024, 2 * ceil(H / 8) <= CUs): the
+ * whole sequence and the Linear run as ONE launch of 2 * ceil(H / 8) workgroups that wait on each other's h every step, so
+ * ALL of them must be resident: do not run two such calls concurrently on one device (two streams / processes can starve
+ * each other of CUs).  The waits are bounded: a call that gives up fills `out` with NaN (and raises an error word inside
+ * its workspace).  vfr_set_option("lstm_persist", 0) selects one launch per step instead.                         */
 size_t vfr_bilstm_workspace_bytes(int64_t B, int T, int E, int H, int vocab);
 int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *emb, int vocab, const float *len_tab,
                          const float *Wih_f, const float *Whh_f, const float *bih_f, const float *bhh_f,
@@ -290,8 +295,14 @@ int vfr_math_f32(int op, const float *x, const float *y, float *out, int64_t n, 
  * launches), "lstm_tile" 0|1|2|3 (fused LSTM step tile rows: automatic | 64 | 128 | 32), "gemm_pp" 0|1 (experimental ping-pong
  * schedule of the large MFMA GEMMs, default 0), "score_pre_b" N (videos in the top-k threshold ladder's stage B; 0 = Nv/16
  * capped at 640), "score_tasks" N (wave-tasks the fused scorer's plan aims for; 0 = automatic), "lstm_skip0" 1|0 (the first LSTM step
- * skips its recurrent segment because h_0 = 0 | runs it), "score_smallq" N (vfr_score_topk_mfma, f32: batches of up to N <= 8 queries against banks of <= 21 clips per video are scored with lanes = clips / videos and a selection tree, default 8; 0: always the fused kernels), "lstm_small" N (batches of up to N <= 4 queries take the vector-chain LSTM step, default 2; 0: always the MFMA tiles), "score_mfma_min" N (vfr_score_topk_mfma hands banks of fewer than N videos to the exact kernels, default 128), "gemm_small" 0|64 (GEMMs of under 384 128-row tiles: 32-row tiles |
- * 64-row tiles), "lstm_xcd" 1|0 (XCD-aware workgroup order of the fused LSTM step | launch order) -- same bits either way.                                                                       */
+ * skips its recurrent segment because h_0 = 0 | runs it), "score_smallq" N (vfr_score_topk_mfma, f32: batches of up to N <= 32 queries against banks of <= 21 clips per video are scored with lanes = clips / videos, the top-k by video selection, default 32; 0: always the fused kernels), "lstm_small" N (batches of up to N <= 4 queries take the vector-chain LSTM step, default 2; 0: always the MFMA tiles), "score_mfma_min" N (vfr_score_topk_mfma hands banks of fewer than N videos to the exact kernels, default 128), "gemm_small" 0|64 (GEMMs of under 384 128-row tiles: 32-row tiles |
+ * 64-row tiles), "lstm_xcd" 1|0 (XCD-aware workgroup order of the fused LSTM step | launch order), "lstm_persist" 1|0 (up to 32
+ * queries: the whole BiLSTM sequence in ONE launch -- one or two queries: weight slices resident in LDS, vector chains; above
+ * "lstm_persist_min" (default 2) at the model's shape: weights resident in registers as MFMA fragments -- with h handed between
+ * workgroups as tagged granules | one launch per step), "score_smallq_select" 1|0 (few-queries top-k by video selection | key
+ * array + selection tree), "vgg_fuse_pool" 1|0 (a 2x2 max-pool behind a VGG convolution runs in that convolution's epilogue |
+ * its own kernel), "vgg_direct1" 1|0 (first VGG convolution as the direct kernel | the implicit-GEMM MFMA kernel)
+ * -- same bits either way.                                                                       */
 int vfr_set_option(const char *name, int value);
 int vfr_get_option(const char *name);
 /* vfr_set_option("profile", 1): every instrumented launch is bracketed by two hipEvents recorded on

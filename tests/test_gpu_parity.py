@@ -495,9 +495,9 @@ def test_file_dataset_pools_on_gpu_and_evaluates(vfr, oracle, golden, mode, tmp_
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nq", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("nq", [1, 2, 3, 5, 8, 13, 32])
 def test_few_queries_scoring_path(vfr, nq):
-    """1-8 queries (a serving request) are scored with lanes = clips / videos; the top-k comes from the videos whose smallest
+    """1-32 queries (a serving request) are scored with lanes = clips / videos; the top-k comes from the videos whose smallest
     clip distance can still reach it (`score_smallq_select`; off: a selection tree over the key array)
     (`score_smallq`): top-k lists and rank counts bit-identical to the fused kernels (option off) and to dense + stable sort;
     ragged clip counts, an empty video, duplicated videos (exact ties), k = 0 / 1 / 100 / more than there are moments, 1-4 rank keys."""
@@ -524,11 +524,11 @@ def test_few_queries_scoring_path(vfr, nq):
             try:
                 vfr.set_option("score_smallq", 0)
                 d2, i2, c2 = vfr.score_topk(Q, bank, k, rd, ri, mode="mfma")
-                vfr.set_option("score_smallq", 8)
+                vfr.set_option("score_smallq", 32)
                 vfr.set_option("score_smallq_select", 0)       # the key array + selection tree instead of the video selection
                 d3, i3, c3 = vfr.score_topk(Q, bank, k, rd, ri, mode="mfma")
             finally:
-                vfr.set_option("score_smallq", 8)
+                vfr.set_option("score_smallq", 32)
                 vfr.set_option("score_smallq_select", 1)
             assert c.tolist() == [[p] * nq for p in pos] and torch.equal(c, c2) and torch.equal(c, c3)
             if k:
@@ -624,11 +624,15 @@ def test_bilstm_few_queries_vector_chain(vfr, oracle, normlang):
     for B in (1, 2, 3, 4):
         try:
             vfr.set_option("lstm_small", 4)
+            vfr.set_option("lstm_persist_min", 32)      # (3 and 4 queries on the vector-chain step, not the MFMA sequence kernel)
             small = vfr.bilstm_final(dev(tokens[:B]), *rest)
             vfr.set_option("lstm_small", 0)
+            vfr.set_option("lstm_persist", 0)
             tiles = vfr.bilstm_final(dev(tokens[:B]), *rest)
         finally:
             vfr.set_option("lstm_small", 2)
+            vfr.set_option("lstm_persist", 1)
+            vfr.set_option("lstm_persist_min", 2)
         assert torch.equal(small.view(torch.int32), tiles.view(torch.int32)), B
         assert same(small, want[:B]), B
         if B <= 2:
@@ -651,6 +655,33 @@ def test_bilstm_few_queries_vector_chain(vfr, oracle, normlang):
             for _ in range(3):
                 again = vfr.bilstm_final(dev(tokens[:B]), *rest)
                 assert torch.equal(small.view(torch.int32), again.view(torch.int32)), B
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("normlang", [False, True])
+def test_bilstm_mid_batches_sequence_kernel(vfr, oracle, normlang):
+    """3-32 queries at the model's shape run the whole BiLSTM sequence in ONE launch on the matrix pipe (lstm_seq_mfma_kernel:
+    weights in registers as MFMA B fragments, h handed between workgroups as tagged granules): same bits as the MFMA tile
+    steps (`lstm_persist` 0) and as the oracle; one and two row tiles, batches that do not fill a tile, an all-pad query,
+    repeated calls (the granule buffers are re-zeroed every call)."""
+    sd = synth.model_weights(4096, seed=17, normalize_lang=normlang)
+    tokens = synth.query_tokens(32, seed=17)
+    tokens[5, :] = 0
+    lt = sd.get("learnable_length.weight")
+    rest = (dev(sd["word_embedding.weight"]), {k: dev(v) for k, v in lstm_of(sd).items()}, dev(sd["lang_fc.weight"]),
+            dev(sd["lang_fc.bias"]), dev(lt) if lt is not None else None)
+    want = oracle.bilstm_final(tokens, sd["word_embedding.weight"], lstm_of(sd), sd["lang_fc.weight"], sd["lang_fc.bias"], lt)
+    for B in (3, 8, 16, 17, 32):
+        seq = vfr.bilstm_final(dev(tokens[:B]), *rest)
+        try:
+            vfr.set_option("lstm_persist", 0)
+            tiles = vfr.bilstm_final(dev(tokens[:B]), *rest)
+        finally:
+            vfr.set_option("lstm_persist", 1)
+        assert torch.equal(seq.view(torch.int32), tiles.view(torch.int32)), B
+        assert same(seq, want[:B]), B
+        again = vfr.bilstm_final(dev(tokens[:B]), *rest)
+        assert torch.equal(seq.view(torch.int32), again.view(torch.int32)), B
 
 
 @pytest.mark.gpu

@@ -639,6 +639,189 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_small_kernel(SeqLstm a)
     if (dead && lane == 0) atomicOr(a.err, 1u);
 }
 
+// ---- 3 .. 32 queries: the same single-launch sequence on the matrix pipe, the weights resident in REGISTERS ------------
+// The MFMA tile step at these batch sizes is one lone workgroup per CU paying a load latency per K-tile: 31-34 us per step
+// whatever the batch.  Here a workgroup again owns 8 hidden units of one direction (32 gate columns); wave (rt, ct) holds column
+// tile ct (16 columns) of [W_ih | W_hh] as the B fragments of all 275 k-steps IN ITS REGISTERS for the whole sequence (275 of
+// the wave's 512: one wave per SIMD) and row tile rt (16 queries) of [x_t | h] comes from LDS as A fragments (row stride 1100
+// floats: 16 rows x 4 k's hit 64 distinct banks).  One v_mfma_f32_16x16x4_f32 per k-step on top of the accumulator = the
+// canonical chain, bit for bit.  Gates meet through LDS, thread (query, unit) finishes its cell (c in a register for the whole
+// sequence), h travels as tagged granules exactly as in lstm_seq_small_kernel; every wave sweeps a quarter of the B x H granules.
+template <int RT, int NCE, int NCH>
+__global__ __launch_bounds__(256, 1) void lstm_seq_mfma_kernel(SeqLstm a)
+{
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int RB = 16 * RT, E = 4 * NCE, H = 4 * (NCH - NCE), KX = E + H, NGL = 16;
+    extern __shared__ __attribute__((aligned(16))) float seq_lds[];
+    float *xh = seq_lds;                  // [RB][KX]: this step's embedded token | the previous step's h, per query
+    float *pre = xh + RB * KX;            // [RB][32] gate pre-activations
+    int &s_dead = *reinterpret_cast<int *>(pre + RB * 32);      // (dynamic too: a static word would push the total past what the attribute admits)
+    float *wrow = pre + RB * 32 + 4;      // [2H] lang_fc row of output blockIdx.x (fused lang_fc only)
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = wv & 1, rt = wv >> 1;
+    const bool comp = rt < RT;
+    const int nblk = (H + 7) / 8, d = blockIdx.x / nblk, u0 = (blockIdx.x % nblk) * 8;
+    const int B = a.B;
+    // ---- the wave's 16 columns of [W_ih | W_hh] -> registers, as the B fragments of the k-steps ----
+    float wreg[NCH];
+    {
+        const int c = ct * 16 + l15;
+        int unit = u0 + (c & 7);
+        unit = unit < H ? unit : H - 1;
+        const size_t row = (size_t)(c >> 3) * H + unit;
+        const float *wi = a.Wih[d] + row * E + lq, *wh = a.Whh[d] + row * H + lq;
+#pragma unroll
+        for (int s = 0; s < NCH; ++s) wreg[s] = comp ? (s < NCE ? wi[4 * s] : wh[4 * (s - NCE)]) : 0.0f;
+    }
+    if (tid == 0) s_dead = 0;
+    // cell of this thread: query tid >> 3, unit u0 + (tid & 7)
+    const int crow = tid >> 3, cu = tid & 7, cunit = u0 + cu;
+    const bool cell = crow < B && crow < RB;
+    const int cuc = cunit < H ? cunit : H - 1;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f}, cst = 0.0f;
+    if (cell) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bsum[g] = a.bih[d][g * H + cuc] + a.bhh[d][g * H + cuc];
+    }
+    const int arow = (rt * 16 + l15) < B ? rt * 16 + l15 : B - 1;          // A rows past the batch repeat the last query
+    const float *ap = xh + arow * KX + lq;
+    const size_t gdir = (size_t)B * H;
+    const int n = B * H;
+    // embedded tokens of the next step, requested a step ahead: RB * E / 256 values per thread
+    constexpr int NX = (RB * E + 255) / 256;
+    float xn[NX];
+    auto xload = [&](int step) {
+        const int t = d ? a.T - 1 - step : step;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            int i = tid + 256 * j;
+            i = i < B * E ? i : B * E - 1;
+            const int xr = i / E, k = i - xr * E;
+            xn[j] = a.X[((size_t)xr * a.T + t) * E + k];
+        }
+    };
+    xload(0);
+    bool dead = false;
+    // every wave sweeps a quarter of the B x H granules of direction dd written at step tag - 1 (tag = that step + 1) into the
+    // h part of the LDS rows, 16 loads in flight per lane, a batch re-read until all its tags match
+    auto sweep = [&](int dd, int tag) {
+        seq_gu64 *gp = (seq_gu64 *)(a.hg + ((size_t)((tag - 1) & 1) * 2 + dd) * gdir);
+        const int per = (n + 3) / 4, g0 = wv * per, g1 = g0 + per < n ? g0 + per : n;
+        for (int base = g0; base < g1 && !dead; base += 64 * NGL) {
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+                unsigned long long gv[NGL];
+#pragma unroll
+                for (int j = 0; j < NGL; ++j) {
+                    const int g = base + lane + 64 * j;
+                    gv[j] = __hip_atomic_load(gp + (g < g1 ? g : g1 - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int j = 0; j < NGL; ++j) {
+                    int g = base + lane + 64 * j;
+                    g = g < g1 ? g : g1 - 1;
+                    ok &= (unsigned)(gv[j] >> 32) == (unsigned)tag;
+                    const int gr = g / H;
+                    xh[gr * KX + E + (g - gr * H)] = __uint_as_float((unsigned)gv[j]);
+                }
+                if (__all(ok)) break;
+                if (spins >= SEQ_MAX_SPINS) { dead = true; s_dead = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    };
+    for (int step = 0; step < a.T; ++step) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            int i = tid + 256 * j;
+            i = i < B * E ? i : B * E - 1;
+            const int xr = i / E, k = i - xr * E;
+            xh[xr * KX + k] = xn[j];
+        }
+        xload(step + 1 < a.T ? step + 1 : step);
+        __syncthreads();                                          // x_t staged (and the previous step's cells are done with `pre`)
+        f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        // k-steps [S0, S1) of the chain: the A fragments of the next group of 8 k-steps are requested (LDS) before the current
+        // group's MFMAs are issued
+        auto chain = [&](auto s0c, auto s1c) {
+            constexpr int S0 = decltype(s0c)::value, S1 = decltype(s1c)::value, GK = 8, NGRP = (S1 - S0 + GK - 1) / GK;
+            float ab[2][GK];
+#pragma unroll
+            for (int j = 0; j < GK; ++j) ab[0][j] = ap[4 * (S0 + j < S1 ? S0 + j : S1 - 1)];
+#pragma unroll
+            for (int g = 0; g < NGRP; ++g) {
+                if (g + 1 < NGRP) {
+#pragma unroll
+                    for (int j = 0; j < GK; ++j) { const int sn = S0 + (g + 1) * GK + j; ab[(g + 1) & 1][j] = ap[4 * (sn < S1 ? sn : S1 - 1)]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < GK; ++j) {
+                    const int sc = S0 + g * GK + j;
+                    if (sc < S1) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[g & 1][j], wreg[sc], acc, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (comp) chain(std::integral_constant<int, 0>{}, std::integral_constant<int, NCE>{});
+        if (step > 0 && !dead) sweep(d, step);
+        __syncthreads();                                          // h of the previous step staged by all four waves
+        dead = dead || s_dead != 0;
+        if (comp && step > 0) chain(std::integral_constant<int, NCE>{}, std::integral_constant<int, NCH>{});
+        if (comp) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pre[(rt * 16 + 4 * lq + r) * 32 + ct * 16 + l15] = acc[r];
+        }
+        __syncthreads();
+        if (cell) {
+            const float *pr = pre + crow * 32 + cu;
+            const float ig = c_sigmoidf(pr[0] + bsum[0]);
+            const float fg = c_sigmoidf(pr[8] + bsum[1]);
+            const float gg = c_tanhf(pr[16] + bsum[2]);
+            const float og = c_sigmoidf(pr[24] + bsum[3]);
+            cst = __builtin_fmaf(fg, cst, ig * gg);
+            float hn = og * c_tanhf(cst);
+            if (dead) hn = __uint_as_float(0x7fc00000u);
+            if (cunit < H) {
+                if (step + 1 < a.T || a.Wfc) {
+                    seq_gu64 *gq = (seq_gu64 *)(a.hg + ((size_t)(step & 1) * 2 + d) * gdir + (size_t)crow * H + cunit);
+                    __hip_atomic_store(gq, ((unsigned long long)(unsigned)(step + 1) << 32) | __float_as_uint(hn),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (step + 1 == a.T) a.hout[(size_t)crow * 2 * H + (size_t)d * H + cunit] = hn;
+            }
+        }
+    }
+    // ---- lang_fc behind the last step: workgroup o < D gathers the final h of every query, one direction at a time (forward
+    // first: the chain runs over [h_fwd | h_bwd], k ascending), into the LDS rows' h part; lane r of wave 0 runs query r's
+    // chain for output o against the row of Wfc staged in LDS, then + bias (gemm_nt's order) ----
+    if (a.Wfc && (int)blockIdx.x < a.D) {
+        const int o = blockIdx.x;
+        for (int i = tid; i < 2 * H / 4; i += 256)
+            *reinterpret_cast<float4 *>(wrow + 4 * i) = *reinterpret_cast<const float4 *>(a.Wfc + (size_t)o * 2 * H + 4 * i);
+        float sfc = 0.0f;
+        for (int dd = 0; dd < 2; ++dd) {
+            __syncthreads();                                      // (the rows' h part is free: last step's chains / previous half are done)
+            if (!dead) sweep(dd, a.T);
+            __syncthreads();
+            dead = dead || s_dead != 0;
+            if (tid < B && tid < RB) {
+                const float *hp = xh + tid * KX + E, *wp = wrow + dd * H;
+#pragma unroll 8
+                for (int k4 = 0; k4 < H / 4; ++k4) {
+                    const float4 w = *reinterpret_cast<const float4 *>(wp + 4 * k4);
+                    const float4 x = *reinterpret_cast<const float4 *>(hp + 4 * k4);
+                    sfc = __builtin_fmaf(x.x, w.x, sfc); sfc = __builtin_fmaf(x.y, w.y, sfc);
+                    sfc = __builtin_fmaf(x.z, w.z, sfc); sfc = __builtin_fmaf(x.w, w.w, sfc);
+                }
+            }
+        }
+        if (tid < B && tid < RB) a.out[(size_t)tid * a.D + o] = dead ? __uint_as_float(0x7fc00000u) : sfc + a.bfc[o];
+    }
+    if (dead && tid == 0) atomicOr(a.err, 1u);
+}
+
 struct LstmWs {
     float *X, *gates, *c, *c2, *hcat, *hcat2, *hfinal, *xv, *wperm, *ptab, *wt;
     unsigned long long *hg;               // persistent sequence kernel: [16 B error word | 2 x 2 x B x H granules]
@@ -675,7 +858,7 @@ static LstmWs carve(void *base, int64_t B, int T, int E, int H, int vocab)
         w.tokidx = reinterpret_cast<int *>(take_b(R * T * sizeof(int)));
     }
     if (B <= 4) w.wt = take((size_t)2 * (E + H) * 4 * H);       // k-major weights of the vector-chain step (a few queries)
-    if (B <= 2) w.hg = reinterpret_cast<unsigned long long *>(take_b(16 + (size_t)4 * B * H * sizeof(unsigned long long)));
+    if (B <= 32) w.hg = reinterpret_cast<unsigned long long *>(take_b(16 + (size_t)4 * B * H * sizeof(unsigned long long)));
     w.total = off;
     return w;
 }
@@ -710,6 +893,43 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
     const int G = 4 * H;
 
     VFR_REQUIRE(T <= 1024, VFR_EUNSUPPORTED, "vfr_bilstm_final_f32: T=%d > 1024", T);
+    if (vfr::opt_lstm_persist() && B > vfr::opt_lstm_persist_min() && B <= 32 && E == 100 && H == 1000 && w.hg &&
+        2 * (int)vfr::cdiv(H, 8) <= vfr::device_cu_count()) {
+        // 3 .. 32 queries at the model's shape: the whole sequence in one launch on the matrix pipe, weights in registers
+        // (lstm_seq_mfma_kernel); every query steps through all T tokens (no sorting, no pad row)
+        const size_t gbytes = 16 + (size_t)4 * B * H * sizeof(unsigned long long);
+        if (hipMemsetAsync(w.hg, 0, gbytes, st) != hipSuccess)
+            return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: buffer initialisation failed");
+        {
+        vfr::ProfScope prof(vfr::SITE_EMBED, st);
+        hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(B * T, 256)), dim3(256), 0, st, tokens, B * T, vocab, emb, len_tab,
+                           E, w.X);
+        }
+        VFR_CHECK_LAUNCH("embed_kernel");
+        const dim3 grid(2 * (unsigned)vfr::cdiv(H, 8));
+        const bool fc_in = D <= (int)grid.x && (((uintptr_t)Wfc) & 15) == 0;        // lang_fc rides in the same launch
+        vfr::SeqLstm a{w.X, {Wih_f, Wih_b}, {Whh_f, Whh_b}, {bih_f, bih_b}, {bhh_f, bhh_b}, w.hg + 2, w.hcat,
+                       reinterpret_cast<unsigned *>(w.hg), (int)B, T, E, H, fc_in ? Wfc : nullptr, bfc, out, D};
+        {
+        vfr::ProfScope prof(vfr::SITE_GEMM_LSTM_REC, st);
+        const int rtiles = B <= 16 ? 1 : 2;
+        const size_t lds = ((size_t)16 * rtiles * (E + H + 32) + 4 + 2 * H) * sizeof(float);
+        static bool attr_done[2] = {false, false};
+        if (rtiles == 1) {
+            if (!attr_done[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vfr::lstm_seq_mfma_kernel<1, 25, 275>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[0] = true; }
+            hipLaunchKernelGGL((vfr::lstm_seq_mfma_kernel<1, 25, 275>), grid, dim3(256), lds, st, a);
+        } else {
+            if (!attr_done[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vfr::lstm_seq_mfma_kernel<2, 25, 275>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[1] = true; }
+            hipLaunchKernelGGL((vfr::lstm_seq_mfma_kernel<2, 25, 275>), grid, dim3(256), lds, st, a);
+        }
+        }
+        VFR_CHECK_LAUNCH("lstm_seq_mfma_kernel");
+        if (fc_in) return VFR_OK;
+        vfr::GemmArgs g{};
+        g.A = w.hcat; g.lda = 2 * H; g.W = Wfc; g.ldw = 2 * H; g.out = out; g.ldo = D; g.M = B; g.N = D; g.K = 2 * H;
+        g.bias = bfc; g.epi = vfr::EPI_BIAS; g.site = vfr::SITE_GEMM_LANG_FC;
+        return vfr::gemm_nt(g, st);
+    }
     if (B <= vfr::opt_lstm_small() && B <= 4 && (E % 4) == 0 && (H % 4) == 0 && w.wt && (size_t)4 * (E + H) * 4 <= 48 * 1024) {
         // a handful of queries: every row steps through all T tokens with the vector-chain step (no sorting, no pad row)
         if (hipMemsetAsync(w.c, 0, (size_t)2 * B * H * sizeof(float), st) != hipSuccess ||

@@ -1853,7 +1853,7 @@ __global__ __launch_bounds__(SQS_THREADS) void smallq_select_kernel(const float 
     }
 }
 
-constexpr int SMALLQ_MAX = 8, SMALLQ_CLIPS = SMALLQ_CLIPS_MAX;
+constexpr int SMALLQ_MAX = 32, SMALLQ_CLIPS = SMALLQ_CLIPS_MAX;
 struct SmallqWs { float *dist; unsigned long long *keys, *bufa, *bufb; float *dmin; int64_t Mpad, P0, P1; size_t total; };
 constexpr int SQ_F1 = 20, SQ_F = 32;        // lists of k per first-level range; fan-in of the later levels
 static SmallqWs carve_smallq(void *base, int64_t Nq, int total_clips, int k)
@@ -2204,10 +2204,15 @@ static int run_smallq(const float *Q, int64_t Nq, const float *V, const int32_t 
     {
         ProfScope prof(SITE_SCORE_FUSED, st);
         const dim3 grid((unsigned)cdiv(total_clips, 256));
-        if (Nq == 1)      hipLaunchKernelGGL(smallq_dist_kernel<1>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
-        else if (Nq == 2) hipLaunchKernelGGL(smallq_dist_kernel<2>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
-        else if (Nq <= 4) hipLaunchKernelGGL(smallq_dist_kernel<4>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
-        else              hipLaunchKernelGGL(smallq_dist_kernel<8>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
+        for (int64_t q0 = 0; q0 < Nq; q0 += 8) {            // eight queries per pass over the bank
+            const int nq = (int)(Nq - q0 < 8 ? Nq - q0 : 8);
+            const float *Qp = Q + q0 * D;
+            float *dp = w.dist + q0 * total_clips;
+            if (nq == 1)      hipLaunchKernelGGL(smallq_dist_kernel<1>, grid, dim3(256), 0, st, Qp, nq, V, total_clips, D, eps, dp);
+            else if (nq == 2) hipLaunchKernelGGL(smallq_dist_kernel<2>, grid, dim3(256), 0, st, Qp, nq, V, total_clips, D, eps, dp);
+            else if (nq <= 4) hipLaunchKernelGGL(smallq_dist_kernel<4>, grid, dim3(256), 0, st, Qp, nq, V, total_clips, D, eps, dp);
+            else              hipLaunchKernelGGL(smallq_dist_kernel<8>, grid, dim3(256), 0, st, Qp, nq, V, total_clips, D, eps, dp);
+        }
         // top-k by video selection (smallq_select_kernel) unless switched off: then the key array + selection tree
         const bool select = k > 0 && opt_score_smallq_select();
         // unwritten key slots (the padding past the last moment) must read as empty: any value >= KEY_EMPTY does
