@@ -498,10 +498,11 @@ def extras(args, dev, model, seg, ctx, clip_off, tokens, make_shard, ranks_of, o
                       "R@1_R@10_R@100_f32": [float((r_f[0] < t).float().mean()) for t in (1, 10, 100)],
                       "R@1_R@10_R@100_bf16": [float((r_b[0] < t).float().mean()) for t in (1, 10, 100)],
                       "median_rank_f32_vs_bf16": [float(r_f[0].float().median()), float(r_b[0].float().median())]}
-        # ---- small query batches (Nq in {1, 64, 1024}): query encoder + labels + scoring against the
-        # resident clip bank (what a serving request costs once the corpus is embedded)
+        # ---- small query batches (Nq in {1, 64, 1024}; 8 and 32 added: up to 32 queries the encoder runs as
+        # ONE launch and the scoring with lanes = clips / videos): query encoder + labels + scoring against the resident clip
+        # bank (what a serving request costs once the corpus is embedded)
         small = {}
-        for nq in (1, 64, 1024):
+        for nq in (1, 8, 32, 64, 1024):
             if nq > Nq:
                 continue
             tk = tokens[:nq].contiguous()

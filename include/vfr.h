@@ -81,7 +81,8 @@ int vfr_linear_f32(const float *A, int64_t M, int K, const float *W, const float
  * for the forward (_f) and reverse (_b) directions; Wfc [D,2H]; out [B,D].
  * The workspace also holds the per-vocabulary input-projection table (emb x W_ih^T, both directions) that the
  * recurrent steps start their gate chains from when vocab <= 32768 -- hence `vocab` in its size.
- * B <= 2 at a shape whose 32-column weight slices fit a CU's LDS (E + H <= 1170, H <= 1024, 2 * ceil(H / 8) <= CUs): the
+ * B <= 2 at a shape whose 32-column weight slices fit a CU's LDS (E + H <= 1170, H <= 1024, 2 * ceil(H / 8) <= CUs), and
+ * 3 <= B <= 32 at E = 100, H = 1000 (weights resident in registers as MFMA fragments): the
  * whole sequence and the Linear run as ONE launch of 2 * ceil(H / 8) workgroups that wait on each other's h every step, so
  * ALL of them must be resident: do not run two such calls concurrently on one device (two streams / processes can starve
  * each other of CUs).  The waits are bounded: a call that gives up fills `out` with NaN (and raises an error word inside

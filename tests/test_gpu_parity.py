@@ -29,12 +29,14 @@ def vfr():
 def score_mode(request, vfr):
     """Every scoring test runs twice: the exact VALU kernels, and the fp32 MFMA pre-filter + exact re-scoring path
     (vfr_score_topk_mfma, dtype f32), whose outputs must be the same bits."""
-    old, old_min = vfr.DEFAULT_SCORE_MODE, vfr.get_option("score_mfma_min")
+    old, old_min, old_sq = vfr.DEFAULT_SCORE_MODE, vfr.get_option("score_mfma_min"), vfr.get_option("score_smallq")
     vfr.DEFAULT_SCORE_MODE = request.param
     vfr.set_option("score_mfma_min", 0)              # the tests' small banks must reach the pre-filter kernels too
+    vfr.set_option("score_smallq", 8)                # ... and their 9-32-query batches (the few-queries path has its own tests)
     yield request.param
     vfr.DEFAULT_SCORE_MODE = old
     vfr.set_option("score_mfma_min", old_min)
+    vfr.set_option("score_smallq", old_sq)
 
 
 def dev(a, dtype=None):
