@@ -687,6 +687,33 @@ def test_bilstm_mid_batches_sequence_kernel(vfr, oracle, normlang):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 5])
+def test_sequence_kernels_give_up_loudly_when_a_workgroup_is_missing(vfr, B):
+    """The single-launch sequence kernels wait on each other's h every step.  Test hook `lstm_persist_fault`: one workgroup
+    withholds its h of step 1 (what a workgroup that never became resident looks like to the others).  The call must RETURN
+    -- bounded sweeps, no hang --, its output must be NaN (loud, not plausible), and the next ordinary call must be right."""
+    import time
+    sd = synth.model_weights(4096, seed=19)
+    tokens = synth.query_tokens(8, seed=19)
+    rest = (dev(sd["word_embedding.weight"]), {k: dev(v) for k, v in lstm_of(sd).items()}, dev(sd["lang_fc.weight"]),
+            dev(sd["lang_fc.bias"]), None)
+    good = vfr.bilstm_final(dev(tokens[:B]), *rest)
+    torch.cuda.synchronize()
+    try:
+        vfr.set_option("lstm_persist_fault", 7)
+        t0 = time.perf_counter()
+        bad = vfr.bilstm_final(dev(tokens[:B]), *rest)
+        torch.cuda.synchronize()
+        took = time.perf_counter() - t0
+    finally:
+        vfr.set_option("lstm_persist_fault", -1)
+    assert took < 20.0
+    assert bool(torch.isnan(bad).all())
+    again = vfr.bilstm_final(dev(tokens[:B]), *rest)
+    assert torch.equal(again.view(torch.int32), good.view(torch.int32))
+
+
+@pytest.mark.gpu
 def test_bilstm_tile_shapes_agree(vfr, oracle):
     """The fused LSTM step picks 32-, 64- or 128-row tiles by batch size; all are the same chains.  Forced either way on one
     batch: identical bits to each other and (on the rows the oracle is run for) to the oracle."""

@@ -414,6 +414,7 @@ struct SeqLstm {
     const float *Wfc, *bfc;               // lang_fc fused behind the last step (nullptr: the caller runs it): [D, 2H], [D]
     float *out;                           // [B, D]
     int D;
+    int fault_block;                      // TEST HOOK (-1: off): this workgroup never publishes its h of step 1 -- the others must give up, not hang
 };
 constexpr int SEQ_WSTRIDE = 33 * 4;       // floats per chunk row: 32 columns x 4 k's + 4 of padding (staging writes conflict-free)
 constexpr unsigned SEQ_MAX_SPINS = 1u << 17;
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_small_kernel(SeqLstm a)
             cst = __builtin_fmaf(fg, cst, ig * gg);
             hn = og * c_tanhf(cst);
             if (dead) hn = __uint_as_float(0x7fc00000u);
-            if (unit < H) {
+            if (unit < H && !(step == 1 && (int)blockIdx.x == a.fault_block)) {
                 if (step + 1 < a.T || a.Wfc) {
                     seq_gu64 *gq = (seq_gu64 *)(a.hg + ((size_t)(step & 1) * 2 + d) * gdir + (size_t)r * H + unit);
                     __hip_atomic_store(gq, ((unsigned long long)(unsigned)(step + 1) << 32) | __float_as_uint(hn),
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_mfma_kernel(SeqLstm a)
             cst = __builtin_fmaf(fg, cst, ig * gg);
             float hn = og * c_tanhf(cst);
             if (dead) hn = __uint_as_float(0x7fc00000u);
-            if (cunit < H) {
+            if (cunit < H && !(step == 1 && (int)blockIdx.x == a.fault_block)) {
                 if (step + 1 < a.T || a.Wfc) {
                     seq_gu64 *gq = (seq_gu64 *)(a.hg + ((size_t)(step & 1) * 2 + d) * gdir + (size_t)crow * H + cunit);
                     __hip_atomic_store(gq, ((unsigned long long)(unsigned)(step + 1) << 32) | __float_as_uint(hn),
@@ -820,6 +821,19 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_mfma_kernel(SeqLstm a)
         if (tid < B && tid < RB) a.out[(size_t)tid * a.D + o] = dead ? __uint_as_float(0x7fc00000u) : sfc + a.bfc[o];
     }
     if (dead && tid == 0) atomicOr(a.err, 1u);
+}
+
+// the sequence kernels declare up to 160 KB of dynamic LDS: asked for once per kernel; a device / runtime that refuses keeps
+// the per-step paths
+template <typename K>
+static bool seq_lds_admitted(K kernel)
+{
+    static int state = -1;
+    if (state < 0) {
+        state = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : 0;
+        if (!state) (void)hipGetLastError();
+    }
+    return state == 1;
 }
 
 struct LstmWs {
@@ -894,7 +908,8 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
 
     VFR_REQUIRE(T <= 1024, VFR_EUNSUPPORTED, "vfr_bilstm_final_f32: T=%d > 1024", T);
     if (vfr::opt_lstm_persist() && B > vfr::opt_lstm_persist_min() && B <= 32 && E == 100 && H == 1000 && w.hg &&
-        2 * (int)vfr::cdiv(H, 8) <= vfr::device_cu_count()) {
+        2 * (int)vfr::cdiv(H, 8) <= vfr::device_cu_count() &&
+        (B <= 16 ? vfr::seq_lds_admitted(vfr::lstm_seq_mfma_kernel<1, 25, 275>) : vfr::seq_lds_admitted(vfr::lstm_seq_mfma_kernel<2, 25, 275>))) {
         // 3 .. 32 queries at the model's shape: the whole sequence in one launch on the matrix pipe, weights in registers
         // (lstm_seq_mfma_kernel); every query steps through all T tokens (no sorting, no pad row)
         const size_t gbytes = 16 + (size_t)4 * B * H * sizeof(unsigned long long);
@@ -909,19 +924,13 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
         const dim3 grid(2 * (unsigned)vfr::cdiv(H, 8));
         const bool fc_in = D <= (int)grid.x && (((uintptr_t)Wfc) & 15) == 0;        // lang_fc rides in the same launch
         vfr::SeqLstm a{w.X, {Wih_f, Wih_b}, {Whh_f, Whh_b}, {bih_f, bih_b}, {bhh_f, bhh_b}, w.hg + 2, w.hcat,
-                       reinterpret_cast<unsigned *>(w.hg), (int)B, T, E, H, fc_in ? Wfc : nullptr, bfc, out, D};
+                       reinterpret_cast<unsigned *>(w.hg), (int)B, T, E, H, fc_in ? Wfc : nullptr, bfc, out, D, vfr::opt_lstm_persist_fault()};
         {
         vfr::ProfScope prof(vfr::SITE_GEMM_LSTM_REC, st);
         const int rtiles = B <= 16 ? 1 : 2;
         const size_t lds = ((size_t)16 * rtiles * (E + H + 32) + 4 + 2 * H) * sizeof(float);
-        static bool attr_done[2] = {false, false};
-        if (rtiles == 1) {
-            if (!attr_done[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vfr::lstm_seq_mfma_kernel<1, 25, 275>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[0] = true; }
-            hipLaunchKernelGGL((vfr::lstm_seq_mfma_kernel<1, 25, 275>), grid, dim3(256), lds, st, a);
-        } else {
-            if (!attr_done[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vfr::lstm_seq_mfma_kernel<2, 25, 275>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[1] = true; }
-            hipLaunchKernelGGL((vfr::lstm_seq_mfma_kernel<2, 25, 275>), grid, dim3(256), lds, st, a);
-        }
+        if (rtiles == 1) hipLaunchKernelGGL((vfr::lstm_seq_mfma_kernel<1, 25, 275>), grid, dim3(256), lds, st, a);
+        else             hipLaunchKernelGGL((vfr::lstm_seq_mfma_kernel<2, 25, 275>), grid, dim3(256), lds, st, a);
         }
         VFR_CHECK_LAUNCH("lstm_seq_mfma_kernel");
         if (fc_in) return VFR_OK;
@@ -944,24 +953,19 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
         // one or two queries at a shape whose 32-column weight slices fit a CU's LDS: the whole sequence in one launch
         const size_t seq_lds = ((size_t)((E + H) / 4) * vfr::SEQ_WSTRIDE + (size_t)(B <= 1 ? 1 : 2) * (H + E + 32)) * sizeof(float);
         const int seq_grid = 2 * (int)vfr::cdiv(H, 8);
-        if (vfr::opt_lstm_persist() && B <= 2 && w.hg && H <= 1024 && 2 * E <= 256 && (((uintptr_t)Wfc) & 15) == 0 && seq_lds <= 160 * 1024 && seq_grid <= vfr::device_cu_count()) {
+        if (vfr::opt_lstm_persist() && B <= 2 && w.hg && H <= 1024 && 2 * E <= 256 && (((uintptr_t)Wfc) & 15) == 0 && seq_lds <= 160 * 1024 && seq_grid <= vfr::device_cu_count() &&
+            (B <= 1 ? vfr::seq_lds_admitted(vfr::lstm_seq_small_kernel<1>) : vfr::seq_lds_admitted(vfr::lstm_seq_small_kernel<2>))) {
             const size_t gbytes = 16 + (size_t)4 * B * H * sizeof(unsigned long long);
             if (hipMemsetAsync(w.hg, 0, gbytes, st) != hipSuccess)
                 return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: buffer initialisation failed");
             // lang_fc rides in the same launch when every output gets a workgroup and the row fits beside the gathered h
             const bool fc_in = D <= seq_grid && (size_t)(1 + (B <= 1 ? 1 : 2)) * 2 * H * sizeof(float) <= seq_lds;
             vfr::SeqLstm a{w.X, {Wih_f, Wih_b}, {Whh_f, Whh_b}, {bih_f, bih_b}, {bhh_f, bhh_b}, w.hg + 2, w.hcat,
-                           reinterpret_cast<unsigned *>(w.hg), (int)B, T, E, H, fc_in ? Wfc : nullptr, bfc, out, D};
+                           reinterpret_cast<unsigned *>(w.hg), (int)B, T, E, H, fc_in ? Wfc : nullptr, bfc, out, D, vfr::opt_lstm_persist_fault()};
             {
             vfr::ProfScope prof(vfr::SITE_GEMM_LSTM_REC, st);
-            static bool attr_done[2] = {false, false};
-            if (B <= 1) {
-                if (!attr_done[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vfr::lstm_seq_small_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[0] = true; }
-                hipLaunchKernelGGL(vfr::lstm_seq_small_kernel<1>, dim3((unsigned)seq_grid), dim3(256), seq_lds, st, a);
-            } else {
-                if (!attr_done[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vfr::lstm_seq_small_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done[1] = true; }
-                hipLaunchKernelGGL(vfr::lstm_seq_small_kernel<2>, dim3((unsigned)seq_grid), dim3(256), seq_lds, st, a);
-            }
+            if (B <= 1) hipLaunchKernelGGL(vfr::lstm_seq_small_kernel<1>, dim3((unsigned)seq_grid), dim3(256), seq_lds, st, a);
+            else        hipLaunchKernelGGL(vfr::lstm_seq_small_kernel<2>, dim3((unsigned)seq_grid), dim3(256), seq_lds, st, a);
             }
             VFR_CHECK_LAUNCH("lstm_seq_small_kernel");
             if (fc_in) return VFR_OK;
