@@ -1702,6 +1702,8 @@ __global__ __launch_bounds__(256) void topk_tree_kernel(const unsigned long long
 //   D  wave 0 runs the pool selection of the merge kernels over the candidates (typically a few hundred) and writes the rows.
 // Exact: the candidates are a superset of the top-k with the dense kernel's keys.
 constexpr int SQS_BINS = 2048, SQS_LIST = 4096, SQS_THREADS = 1024;
+static_assert(SQS_BINS == 2 * SQS_THREADS, "the bin scan gives every thread two bins");
+static_assert(SQS_LIST >= 2 * SQS_THREADS, "the video list must take at least one full chunk of candidates after a partial one");
 template <int KPL>
 __global__ __launch_bounds__(SQS_THREADS) void smallq_select_kernel(const float *__restrict__ dist, const float *__restrict__ dmin,
                                                                     const int32_t *__restrict__ clip_off, const int64_t *__restrict__ mom_off,
