@@ -111,6 +111,13 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
 #ifndef VFR_GEMM_SETPRIO
 #define VFR_GEMM_SETPRIO 0
 #endif
+#ifndef VFR_GEMM_DEEP
+#define VFR_GEMM_DEEP 0      // 1: two staging register sets, K-tiles kt + 2 and kt + 3 in flight (see DEEP in the kernel body); 0: one.
+                             // EXPERIMENT (round 3): bit-identical, +20..32 VGPRs, and no faster anywhere -- the fused LSTM step at 64 / 200 /
+                             // 625 / 1250 / 5000 queries 0.745 / 0.953 / 1.80 / 3.10 / 10.09 ms per pass against 0.730 / 0.955 / 1.81 / 3.09 /
+                             // 10.16 with one set: the small-batch step is not waiting for its staging loads (nor for its fragment reads:
+                             // VFR_LSTM_DEPTH 2 changes nothing either).  Off.
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int MBM = 128, MBN = 128, MBK = 32, MLD_PAD = 36;
 
@@ -259,13 +266,19 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         }
     };
 
-    float4 ra[NA], rw[NW];
+    // staging registers: two sets in the software-pipelined loop (DEEP: K-tile kt + 2 is in flight in one set while kt + 3 is
+    // requested into the other -- 1 3/4 tiles of cover for the load latency instead of 3/4: it is what a 32-row tile, whose MFMA
+    // block is short, needs to keep enough bytes in flight), one set otherwise
+    constexpr bool DEEP = VFR_GEMM_DEEP && !PP && (LSTM ? VFR_LSTM_NBUF : VFR_GEMM_NBUF) == 2 && VFR_GEMM_PIPE;
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    float4 ra[DEEP ? 2 : 1][NA], rw[DEEP ? 2 : 1][NW];
     // Zero-fill of staged elements outside the operand (conv padding taps, the tail of a segmented K) is decided when the
     // load is ISSUED but applied (to the A side only) when the registers are written to LDS: a select right after the load
     // would make hipcc wait for the load (vmcnt(0)) before the MFMA block and expose its latency in every K-tile.
-    bool za[NA];
+    bool za[DEEP ? 2 : 1][NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) za[i] = false;
+    for (int i = 0; i < NA; ++i) { za[0][i] = false; za[DEEP ? 1 : 0][i] = false; }
     // Staging loads.  Full K-tiles use UNCONDITIONAL loads (row index clamped into range; rows past M / N are
     // never stored) so the compiler can leave them in flight across the MFMA block -- a per-load bounds branch
     // makes hipcc drain vmcnt(0) right after issuing them.  Only the last, partial K-tile takes the guarded form.
@@ -304,7 +317,8 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         arow[i] = CONV ? g.A : g.A + ma * g.lda + kk;
         if (!LSTM && !CONV) aoff1[i] = (unsigned)(((ma - m0) * g.lda + kk) * 4);
     }
-    auto gload_full = [&](int k0) {
+    auto gload_full = [&](int k0, auto sc) {
+        constexpr int S = decltype(sc)::value;
         // aligned operands: uniform tile base (scalar registers) + the thread's fixed 32-bit offset inside the tile's rows
         // (at most 127 rows of lda floats: gemm_nt checks that this fits 32 bits) -- no vector address arithmetic per K-tile
         const char *ba = reinterpret_cast<const char *>(g.A + m0 * g.lda + k0);
@@ -314,26 +328,27 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             asm volatile("" : "+v"(aoff1[i]));
-            if (VEC) ra[i] = *reinterpret_cast<const float4 *>(ba + aoff1[i]);
-            else     ra[i] = make_float4(arow[i][k0], arow[i][k0 + 1], arow[i][k0 + 2], arow[i][k0 + 3]);
+            if (VEC) ra[S][i] = *reinterpret_cast<const float4 *>(ba + aoff1[i]);
+            else     ra[S][i] = make_float4(arow[i][k0], arow[i][k0 + 1], arow[i][k0 + 2], arow[i][k0 + 3]);
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             asm volatile("" : "+v"(woff1[i]));
-            if (VEC) rw[i] = *reinterpret_cast<const float4 *>(bw + woff1[i]);
-            else     rw[i] = make_float4(wrow[i][k0], wrow[i][k0 + 1], wrow[i][k0 + 2], wrow[i][k0 + 3]);
+            if (VEC) rw[S][i] = *reinterpret_cast<const float4 *>(bw + woff1[i]);
+            else     rw[S][i] = make_float4(wrow[i][k0], wrow[i][k0 + 1], wrow[i][k0 + 2], wrow[i][k0 + 3]);
         }
     };
-    auto gload_tail = [&](int k0) {
+    auto gload_tail = [&](int k0, auto sc) {
+        constexpr int S = decltype(sc)::value;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
-            ra[i] = load4_guard<false>(g.A, g.lda, m0 + row, g.M, k0 + kk, g.K);
+            ra[S][i] = load4_guard<false>(g.A, g.lda, m0 + row, g.M, k0 + kk, g.K);
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
-            rw[i] = load4_guard<false>(g.W, g.ldw, (int64_t)n0 + row, g.N, k0 + kk, g.K);
+            rw[S][i] = load4_guard<false>(g.W, g.ldw, (int64_t)n0 + row, g.N, k0 + kk, g.K);
         }
     };
     // ---- implicit-GEMM conv loader: per staged row the output pixel is fixed, per K-tile the thread's 4 consecutive
@@ -402,7 +417,8 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         }
     }
     const int ctpt = CFAST ? g.conv_cin / MBK : 1;                      // K-tiles per tap
-    auto gload_conv_fast = [&](int k0) {
+    auto gload_conv_fast = [&](int k0, auto sc) {
+        constexpr int S = decltype(sc)::value;
         const int kt = k0 / MBK, tap = kt / ctpt, ci0 = (kt - tap * ctpt) * MBK;
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;             // tap / 3 for tap < 9
         const int dpix = (ky - 1) * g.conv_w + (kx - 1);
@@ -414,16 +430,17 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         for (int i = 0; i < NA; ++i) {
             const bool ok = (ctap[i] & tbit) != 0;
             // outside the image: the row's own pixel (always inside), zeroed when the registers go to LDS
-            ra[i] = *reinterpret_cast<const float4 *>(ba + (ok ? coffb[i] : coffb[i] - dbytes));
-            za[i] = !ok;
+            ra[S][i] = *reinterpret_cast<const float4 *>(ba + (ok ? coffb[i] : coffb[i] - dbytes));
+            za[S][i] = !ok;
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             asm volatile("" : "+v"(woff1[i]));
-            rw[i] = *reinterpret_cast<const float4 *>(bw + woff1[i]);
+            rw[S][i] = *reinterpret_cast<const float4 *>(bw + woff1[i]);
         }
     };
-    auto gload_conv = [&](int k0) {
+    auto gload_conv = [&](int k0, auto sc) {
+        constexpr int S = decltype(sc)::value;
         const int kk = (tid & 7) * 4, k = k0 + kk;
         const bool kok = k < g.K;
         const int kc = kok ? k : 0;
@@ -433,11 +450,11 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             const int iy = coy[i] + ky - 1, ix = cox[i] + kx - 1;
             const bool ok = kok && crow_ok[i] && iy >= 0 && iy < g.conv_h && ix >= 0 && ix < g.conv_w;
             const int64_t off = ok ? (((int64_t)cn[i] * g.conv_h + iy) * g.conv_w + ix) * g.conv_cin + ci : 0;
-            ra[i] = *reinterpret_cast<const float4 *>(g.A + off);
-            za[i] = !ok;
+            ra[S][i] = *reinterpret_cast<const float4 *>(g.A + off);
+            za[S][i] = !ok;
         }
 #pragma unroll
-        for (int i = 0; i < NW; ++i) rw[i] = *reinterpret_cast<const float4 *>(wrow[i] - kk + kc);    // row clamped, k clamped
+        for (int i = 0; i < NW; ++i) rw[S][i] = *reinterpret_cast<const float4 *>(wrow[i] - kk + kc);    // row clamped, k clamped
     };
     // ---- segmented-K loader (LSTM step): tiles [0, nk1) walk [A | W] over K, tiles [nk1, nk1+nk2) walk [A2 | W2] over K2.
     // A partial last tile of a segment is shifted BACK to end exactly at the segment's end (nothing is read past a row);
@@ -445,7 +462,8 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // the finite w re-read beside them), and so are the lanes past the end of a segment shorter than one tile.
     const int nk1 = (g.K + MBK - 1) / MBK;
     bool zq = false;
-    auto gload_seg = [&](int k0t) {
+    auto gload_seg = [&](int k0t, auto sc) {
+        constexpr int S = decltype(sc)::value;
         const int kt = k0t / MBK;
         const bool second = kt >= nk1;
         const int Kseg = second ? g.K2 : g.K, kseg = (second ? kt - nk1 : kt) * MBK;
@@ -456,11 +474,11 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         const char *bw = reinterpret_cast<const char *>((second ? g.W2 : g.W) + kb);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            ra[i] = *reinterpret_cast<const float4 *>(ba + (second ? aoff2[i] : aoff1[i]));
-            za[i] = zq;
+            ra[S][i] = *reinterpret_cast<const float4 *>(ba + (second ? aoff2[i] : aoff1[i]));
+            za[S][i] = zq;
         }
 #pragma unroll
-        for (int i = 0; i < NW; ++i) rw[i] = *reinterpret_cast<const float4 *>(bw + (second ? woff2[i] : woff1[i]));
+        for (int i = 0; i < NW; ++i) rw[S][i] = *reinterpret_cast<const float4 *>(bw + (second ? woff2[i] : woff1[i]));
     };
     // LSTM step on the projection table (K == 0) with a short remainder of the recurrent segment (H = 1000: 31 K-tiles + 8):
     // the remainder does not get a K-tile of its own (a shifted-back tile is 24 zero products in 32 -- 2.3 % of the launch's
@@ -503,26 +521,27 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     };
     const int nk_full = LSTM ? nk1 + (ktail ? g.K2 / MBK : (g.K2 + MBK - 1) / MBK)
                              : CONV ? (g.K + MBK - 1) / MBK : g.K / MBK;     // conv / lstm: every tile through a select loader
-    auto swrite = [&](int b) {
+    auto swrite = [&](int b, auto sc) {
+        constexpr int S = decltype(sc)::value;
         float *As = lds + b * BUF_FLOATS, *Ws = As + A_FLOATS;
 #ifdef VFR_GEMM_NOSWRITE      /* TIMING EXPERIMENT ONLY (wrong results): staged registers are consumed but never written to LDS */
 #pragma unroll
-        for (int i = 0; i < NA; ++i) asm volatile("" :: "v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w));
+        for (int i = 0; i < NA; ++i) asm volatile("" :: "v"(ra[S][i].x), "v"(ra[S][i].y), "v"(ra[S][i].z), "v"(ra[S][i].w));
 #pragma unroll
-        for (int i = 0; i < NW; ++i) asm volatile("" :: "v"(rw[i].x), "v"(rw[i].y), "v"(rw[i].z), "v"(rw[i].w));
+        for (int i = 0; i < NW; ++i) asm volatile("" :: "v"(rw[S][i].x), "v"(rw[S][i].y), "v"(rw[S][i].z), "v"(rw[S][i].w));
         return;
 #endif
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
-            float4 v = ra[i];
-            if (CONV || LSTM) { const bool z = za[i]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
+            float4 v = ra[S][i];
+            if (CONV || LSTM) { const bool z = za[S][i]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
             *reinterpret_cast<float4 *>(&As[lds_off(row, kk)]) = v;
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
-            float4 v = rw[i];
+            float4 v = rw[S][i];
             // (W is not zero-filled: wherever a k lies outside the operand the A side is zero, and the weight re-read from a
             // clamped address beside it is finite, so the product leaves the chain as it is)
             *reinterpret_cast<float4 *>(&Ws[lds_off(row, kk)]) = v;
@@ -571,20 +590,20 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // main loop over the FULL K-tiles, branch-free: iteration kt prefetches tile min(kt+1, last) (the final
     // iteration re-reads its own tile, which is harmless) so no control-flow join sits between the loads and the
     // MFMA block -- a join there makes the compiler drain vmcnt(0) before the first MFMA.
-    auto gload_main = [&](int k0) { if (LSTM) gload_seg(k0); else if (CFAST) gload_conv_fast(k0); else if (CONV) gload_conv(k0); else gload_full(k0); };
+    auto gload_main = [&](int k0, auto sc) { if (LSTM) gload_seg(k0, sc); else if (CFAST) gload_conv_fast(k0, sc); else if (CONV) gload_conv(k0, sc); else gload_full(k0, sc); };
     if (PP) {
         // group g runs  C0 L1 C1 L2 ... C(nk-1)  delayed by g phases;  Ck = MFMA block on K-tile k (LDS), Lk = K-tile k from
         // registers to LDS + issue the loads of K-tile k+1.  One workgroup barrier per phase.
         const int nk = nk_full;
         init_acc();
-        if (active && nk > 0) { gload_main(0); swrite(0); if (nk > 1) gload_main(MBK); }
+        if (active && nk > 0) { gload_main(0, S0); swrite(0, S0); if (nk > 1) gload_main(MBK, S0); }
         __syncthreads();
         GSTAMP(0)
         for (int p = 0; p < 2 * nk; ++p) {
             const int q = p - grp;
             if (active && q >= 0 && q < 2 * nk - 1) {
                 const int k = q >> 1;
-                if (q & 1) { swrite(0); if (k + 2 < nk) gload_main((k + 2) * MBK); }
+                if (q & 1) { swrite(0, S0); if (k + 2 < nk) gload_main((k + 2) * MBK, S0); }
                 else compute(0);
             }
             __syncthreads();
@@ -612,9 +631,24 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         };
         // the first K-tile's loads are in flight while the accumulators are initialised (C-in / the LSTM table gather: two
         // dependent load rounds whose latency would otherwise stand alone at the head of every tile)
-        if (nk > 0) gload_main(0);
+        if (nk > 0) gload_main(0, S0);
         init_acc();
-        if (nk > 0) { swrite(0); gload_main((nk > 1 ? 1 : 0) * MBK); }
+        // Accumulators that start from LOADED values (C-in, the LSTM projection-table gather) must have landed before the loop is
+        // entered: otherwise the waitcnt pass, merging the loop-entry state into the loop header, guards the first MFMAs of EVERY
+        // trip with vmcnt(3) .. vmcnt(0) -- which on the back edge drains the staging loads requested five slices earlier, i.e. the
+        // prefetch is thrown away every second K-tile (seen in the ISA of lstm_step_mfma_pair).  The values are needed by the
+        // first MFMA anyway; waiting here, before K-tile 1 is requested, costs nothing.
+        // (unconditional: behind a run-time test the wait would itself sit on one arm of a join)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                                    // vmcnt(0)
+        if (nk > 0) {
+            swrite(0, S0);
+            if constexpr (DEEP) {        // K-tile 1 into set 1, K-tile 2 into set 0 (free again): two tiles in flight from here on
+                gload_main((nk > 1 ? 1 : 0) * MBK, S1);
+                gload_main((nk > 2 ? 2 : nk - 1) * MBK, S0);
+            } else {
+                gload_main((nk > 1 ? 1 : 0) * MBK, S0);
+            }
+        }
         __syncthreads();
         GSTAMP(0)
         if (nk > 0) {
@@ -640,8 +674,14 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                     for (int tj = 0; tj < 4; ++tj)
                         acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k4 % RING][ti], fb[k4 % RING][tj], acc[ti][tj], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (k4 == 1) swrite(nb);
-                if (k4 == VFR_GLOAD_SLICE) { const int t2 = kt + 2 < nk ? kt + 2 : nk - 1; gload_main(t2 * MBK); }
+                // DEEP: K-tile kt + 1 sits in register set nb (= its parity); once it is in LDS that set takes K-tile kt + 3,
+                // while set cb still holds K-tile kt + 2 in flight
+                if (k4 == 1) swrite(nb, std::integral_constant<int, DEEP ? nb : 0>{});
+                if (k4 == VFR_GLOAD_SLICE) {
+                    const int ahead = DEEP ? 3 : 2;
+                    const int t2 = kt + ahead < nk ? kt + ahead : nk - 1;
+                    gload_main(t2 * MBK, std::integral_constant<int, DEEP ? nb : 0>{});
+                }
             }
         };
         int kt = 0;
@@ -652,19 +692,19 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         if (kt < nk) ktile(kt, std::integral_constant<int, 0>{});
         if (!CONV && !LSTM && (g.K % MBK)) {   // partial last tile: guarded loads, zero padded (fma(0,0,acc) == acc)
             __syncthreads();
-            gload_tail(nk_full * MBK);
-            swrite(0);
+            gload_tail(nk_full * MBK, S0);
+            swrite(0, S0);
             __syncthreads();
             compute(0);
         }
     } else {
     init_acc();
-    if (nk_full > 0) { gload_main(0); swrite(0); }
+    if (nk_full > 0) { gload_main(0, S0); swrite(0, S0); }
     __syncthreads();
     GSTAMP(0)
     for (int kt = 0; kt < nk_full; ++kt) {
         const int nxt = kt + 1 < nk_full ? kt + 1 : nk_full - 1;
-        gload_main(nxt * MBK);
+        gload_main(nxt * MBK, S0);
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMA block (hipcc sinks it otherwise)
         if (VFR_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(1);
         compute(kt % NBUF);
@@ -673,14 +713,14 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         // the other buffer was last read in iteration kt-1 and every wave has passed that iteration's barrier:
         // refill it now (overlapping the other waves' MFMAs); one barrier per K-tile
         if (NBUF == 1) __syncthreads();     // single buffer: everyone must finish reading before the refill
-        swrite((kt + 1) % NBUF);
+        swrite((kt + 1) % NBUF, S0);
 #ifndef VFR_GEMM_NOSYNC
         __syncthreads();
 #endif
     }
     if (!CONV && !LSTM && (g.K % MBK)) {   // partial last tile: guarded loads, zero padded (fma(0,0,acc) == acc)
-        gload_tail(nk_full * MBK);
-        swrite(nk_full % NBUF);
+        gload_tail(nk_full * MBK, S0);
+        swrite(nk_full % NBUF, S0);
         __syncthreads();
         compute(nk_full % NBUF);
     }
