@@ -662,19 +662,24 @@ def test_bilstm_few_queries_vector_chain(vfr, oracle, normlang):
 @pytest.mark.gpu
 @pytest.mark.parametrize("normlang", [False, True])
 def test_bilstm_mid_batches_sequence_kernel(vfr, oracle, normlang):
-    """3-32 queries at the model's shape run the whole BiLSTM sequence in ONE launch on the matrix pipe (lstm_seq_mfma_kernel:
+    """3-64 queries at the model's shape run the whole BiLSTM sequence in ONE launch on the matrix pipe (lstm_seq_mfma_kernel:
     weights in registers as MFMA B fragments, h handed between workgroups as tagged granules): same bits as the MFMA tile
     steps (`lstm_persist` 0) and as the oracle; one and two row tiles, batches that do not fill a tile, an all-pad query,
     repeated calls (the granule buffers are re-zeroed every call)."""
     sd = synth.model_weights(4096, seed=17, normalize_lang=normlang)
-    tokens = synth.query_tokens(32, seed=17)
+    tokens = synth.query_tokens(64, seed=17)
     tokens[5, :] = 0
+    tokens[40, :] = 0
     lt = sd.get("learnable_length.weight")
     rest = (dev(sd["word_embedding.weight"]), {k: dev(v) for k, v in lstm_of(sd).items()}, dev(sd["lang_fc.weight"]),
             dev(sd["lang_fc.bias"]), dev(lt) if lt is not None else None)
     want = oracle.bilstm_final(tokens, sd["word_embedding.weight"], lstm_of(sd), sd["lang_fc.weight"], sd["lang_fc.bias"], lt)
-    for B in (3, 8, 16, 17, 32):
-        seq = vfr.bilstm_final(dev(tokens[:B]), *rest)
+    for B in (3, 8, 16, 17, 32, 33, 49, 64):            # (above 32: two parts taking turns on the same resident weights -- an
+        vfr.set_option("lstm_persist_max", 64)           #  option, slower than the tile steps there: default limit 32)
+        try:
+            seq = vfr.bilstm_final(dev(tokens[:B]), *rest)
+        finally:
+            vfr.set_option("lstm_persist_max", 32)
         try:
             vfr.set_option("lstm_persist", 0)
             tiles = vfr.bilstm_final(dev(tokens[:B]), *rest)
@@ -682,8 +687,9 @@ def test_bilstm_mid_batches_sequence_kernel(vfr, oracle, normlang):
             vfr.set_option("lstm_persist", 1)
         assert torch.equal(seq.view(torch.int32), tiles.view(torch.int32)), B
         assert same(seq, want[:B]), B
-        again = vfr.bilstm_final(dev(tokens[:B]), *rest)
-        assert torch.equal(seq.view(torch.int32), again.view(torch.int32)), B
+        if B <= 32:
+            again = vfr.bilstm_final(dev(tokens[:B]), *rest)
+            assert torch.equal(seq.view(torch.int32), again.view(torch.int32)), B
 
 
 @pytest.mark.gpu

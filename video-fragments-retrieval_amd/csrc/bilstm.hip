@@ -648,13 +648,16 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_small_kernel(SeqLstm a)
 // floats: 16 rows x 4 k's hit 64 distinct banks).  One v_mfma_f32_16x16x4_f32 per k-step on top of the accumulator = the
 // canonical chain, bit for bit.  Gates meet through LDS, thread (query, unit) finishes its cell (c in a register for the whole
 // sequence), h travels as tagged granules exactly as in lstm_seq_small_kernel; every wave sweeps a quarter of the B x H granules.
-template <int RT, int NCE, int NCH>
+// NP > 1: the batch is run as NP parts of up to 16 RT queries that take turns on the same register-resident weights and the same
+// LDS rows (33 .. 64 queries: two parts).  A part's step needs only THAT part's h of the previous step, which every workgroup
+// published before it went on to the other part -- the hand-off of one part travels while the other computes.
+template <int RT, int NP, int NCE, int NCH>
 __global__ __launch_bounds__(256, 1) void lstm_seq_mfma_kernel(SeqLstm a)
 {
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
     constexpr int RB = 16 * RT, E = 4 * NCE, H = 4 * (NCH - NCE), KX = E + H, NGL = 16;
     extern __shared__ __attribute__((aligned(16))) float seq_lds[];
-    float *xh = seq_lds;                  // [RB][KX]: this step's embedded token | the previous step's h, per query
+    float *xh = seq_lds;                  // [RB][KX]: this step's embedded token | the previous step's h, per query of the part
     float *pre = xh + RB * KX;            // [RB][32] gate pre-activations
     int &s_dead = *reinterpret_cast<int *>(pre + RB * 32);      // (dynamic too: a static word would push the total past what the attribute admits)
     float *wrow = pre + RB * 32 + 4;      // [2H] lang_fc row of output blockIdx.x (fused lang_fc only)
@@ -676,39 +679,36 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_mfma_kernel(SeqLstm a)
         for (int s = 0; s < NCH; ++s) wreg[s] = comp ? (s < NCE ? wi[4 * s] : wh[4 * (s - NCE)]) : 0.0f;
     }
     if (tid == 0) s_dead = 0;
-    // cell of this thread: query tid >> 3, unit u0 + (tid & 7)
+    // cell of this thread: query (part row0 +) tid >> 3, unit u0 + (tid & 7)
     const int crow = tid >> 3, cu = tid & 7, cunit = u0 + cu;
-    const bool cell = crow < B && crow < RB;
     const int cuc = cunit < H ? cunit : H - 1;
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f}, cst = 0.0f;
-    if (cell) {
+    float bsum[4], cst[NP];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bsum[g] = a.bih[d][g * H + cuc] + a.bhh[d][g * H + cuc];
-    }
-    const int arow = (rt * 16 + l15) < B ? rt * 16 + l15 : B - 1;          // A rows past the batch repeat the last query
-    const float *ap = xh + arow * KX + lq;
+    for (int g = 0; g < 4; ++g) bsum[g] = a.bih[d][g * H + cuc] + a.bhh[d][g * H + cuc];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) cst[pp] = 0.0f;
     const size_t gdir = (size_t)B * H;
-    const int n = B * H;
-    // embedded tokens of the next step, requested a step ahead: RB * E / 256 values per thread
+    auto rows_of = [&](int pp) { const int left = B - pp * RB; return left < RB ? (left > 0 ? left : 0) : RB; };
+    // embedded tokens of the next step, requested a step ahead: RB * E / 256 values per thread and part
     constexpr int NX = (RB * E + 255) / 256;
-    float xn[NX];
-    auto xload = [&](int step) {
-        const int t = d ? a.T - 1 - step : step;
+    float xn[NP][NX];
+    auto xload = [&](int step, auto pc) {
+        constexpr int pp = decltype(pc)::value;
+        const int t = d ? a.T - 1 - step : step, nr = rows_of(pp), lim = nr > 0 ? nr * E : 1;
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             int i = tid + 256 * j;
-            i = i < B * E ? i : B * E - 1;
+            i = i < lim ? i : lim - 1;
             const int xr = i / E, k = i - xr * E;
-            xn[j] = a.X[((size_t)xr * a.T + t) * E + k];
+            xn[pp][j] = a.X[((size_t)(pp * RB + xr < B ? pp * RB + xr : B - 1) * a.T + t) * E + k];
         }
     };
-    xload(0);
     bool dead = false;
-    // every wave sweeps a quarter of the B x H granules of direction dd written at step tag - 1 (tag = that step + 1) into the
-    // h part of the LDS rows, 16 loads in flight per lane, a batch re-read until all its tags match
-    auto sweep = [&](int dd, int tag) {
-        seq_gu64 *gp = (seq_gu64 *)(a.hg + ((size_t)((tag - 1) & 1) * 2 + dd) * gdir);
-        const int per = (n + 3) / 4, g0 = wv * per, g1 = g0 + per < n ? g0 + per : n;
+    // every wave sweeps a quarter of the part's rows x H granules of direction dd written at step tag - 1 (tag = that step + 1)
+    // into the h part of the LDS rows, 16 loads in flight per lane, a batch re-read until all its tags match
+    auto sweep = [&](int dd, int tag, int row0, int nr) {
+        seq_gu64 *gp = (seq_gu64 *)(a.hg + ((size_t)((tag - 1) & 1) * 2 + dd) * gdir + (size_t)row0 * H);
+        const int n = nr * H, per = (n + 3) / 4, g0 = wv * per, g1 = g0 + per < n ? g0 + per : n;
         for (int base = g0; base < g1 && !dead; base += 64 * NGL) {
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
@@ -732,16 +732,24 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_mfma_kernel(SeqLstm a)
             }
         }
     };
-    for (int step = 0; step < a.T; ++step) {
+    auto part_step = [&](int step, auto pc) {
+        constexpr int pp = decltype(pc)::value;
+        const int row0 = pp * RB, nr = rows_of(pp);
+        if (nr <= 0) return;                                       // (uniform over the workgroup)
+        {
+            const int lim = nr * E;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            int i = tid + 256 * j;
-            i = i < B * E ? i : B * E - 1;
-            const int xr = i / E, k = i - xr * E;
-            xh[xr * KX + k] = xn[j];
+            for (int j = 0; j < NX; ++j) {
+                int i = tid + 256 * j;
+                i = i < lim ? i : lim - 1;
+                const int xr = i / E, k = i - xr * E;
+                xh[xr * KX + k] = xn[pp][j];
+            }
         }
-        xload(step + 1 < a.T ? step + 1 : step);
-        __syncthreads();                                          // x_t staged (and the previous step's cells are done with `pre`)
+        xload(step + 1 < a.T ? step + 1 : step, pc);
+        __syncthreads();                                          // x_t staged (and the previous cells are done with `pre`)
+        const int arow = (rt * 16 + l15) < nr ? rt * 16 + l15 : nr - 1;     // A rows past the part repeat its last query
+        const float *ap = xh + arow * KX + lq;
         f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
         // k-steps [S0, S1) of the chain: the A fragments of the next group of 8 k-steps are requested (LDS) before the current
         // group's MFMAs are issued
@@ -766,7 +774,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_mfma_kernel(SeqLstm a)
             }
         };
         if (comp) chain(std::integral_constant<int, 0>{}, std::integral_constant<int, NCE>{});
-        if (step > 0 && !dead) sweep(d, step);
+        if (step > 0 && !dead) sweep(d, step, row0, nr);
         __syncthreads();                                          // h of the previous step staged by all four waves
         dead = dead || s_dead != 0;
         if (comp && step > 0) chain(std::integral_constant<int, NCE>{}, std::integral_constant<int, NCH>{});
@@ -775,25 +783,33 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_mfma_kernel(SeqLstm a)
             for (int r = 0; r < 4; ++r) pre[(rt * 16 + 4 * lq + r) * 32 + ct * 16 + l15] = acc[r];
         }
         __syncthreads();
-        if (cell) {
+        if (crow < nr) {
             const float *pr = pre + crow * 32 + cu;
             const float ig = c_sigmoidf(pr[0] + bsum[0]);
             const float fg = c_sigmoidf(pr[8] + bsum[1]);
             const float gg = c_tanhf(pr[16] + bsum[2]);
             const float og = c_sigmoidf(pr[24] + bsum[3]);
-            cst = __builtin_fmaf(fg, cst, ig * gg);
-            float hn = og * c_tanhf(cst);
+            cst[pp] = __builtin_fmaf(fg, cst[pp], ig * gg);
+            float hn = og * c_tanhf(cst[pp]);
             if (dead) hn = __uint_as_float(0x7fc00000u);
+            const int grow = row0 + crow;
             if (cunit < H && !(step == 1 && (int)blockIdx.x == a.fault_block)) {
                 if (step + 1 < a.T || a.Wfc) {
-                    seq_gu64 *gq = (seq_gu64 *)(a.hg + ((size_t)(step & 1) * 2 + d) * gdir + (size_t)crow * H + cunit);
+                    seq_gu64 *gq = (seq_gu64 *)(a.hg + ((size_t)(step & 1) * 2 + d) * gdir + (size_t)grow * H + cunit);
                     __hip_atomic_store(gq, ((unsigned long long)(unsigned)(step + 1) << 32) | __float_as_uint(hn),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (step + 1 == a.T) a.hout[(size_t)crow * 2 * H + (size_t)d * H + cunit] = hn;
+                if (step + 1 == a.T) a.hout[(size_t)grow * 2 * H + (size_t)d * H + cunit] = hn;
             }
         }
+    };
+    xload(0, std::integral_constant<int, 0>{});
+    if constexpr (NP > 1) xload(0, std::integral_constant<int, 1>{});
+    for (int step = 0; step < a.T; ++step) {
+        part_step(step, std::integral_constant<int, 0>{});
+        if constexpr (NP > 1) part_step(step, std::integral_constant<int, 1>{});
     }
+    static_assert(NP <= 2, "parts written out for two");
     // ---- lang_fc behind the last step: workgroup o < D gathers the final h of every query, one direction at a time (forward
     // first: the chain runs over [h_fwd | h_bwd], k ascending), into the LDS rows' h part; lane r of wave 0 runs query r's
     // chain for output o against the row of Wfc staged in LDS, then + bias (gemm_nt's order) ----
@@ -801,24 +817,28 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_mfma_kernel(SeqLstm a)
         const int o = blockIdx.x;
         for (int i = tid; i < 2 * H / 4; i += 256)
             *reinterpret_cast<float4 *>(wrow + 4 * i) = *reinterpret_cast<const float4 *>(a.Wfc + (size_t)o * 2 * H + 4 * i);
-        float sfc = 0.0f;
-        for (int dd = 0; dd < 2; ++dd) {
-            __syncthreads();                                      // (the rows' h part is free: last step's chains / previous half are done)
-            if (!dead) sweep(dd, a.T);
-            __syncthreads();
-            dead = dead || s_dead != 0;
-            if (tid < B && tid < RB) {
-                const float *hp = xh + tid * KX + E, *wp = wrow + dd * H;
+        for (int pp = 0; pp < NP; ++pp) {
+            const int row0 = pp * RB, nr = rows_of(pp);
+            if (nr <= 0) break;
+            float sfc = 0.0f;
+            for (int dd = 0; dd < 2; ++dd) {
+                __syncthreads();                                  // (the rows' h part is free: the last chains / the previous gather are done)
+                if (!dead) sweep(dd, a.T, row0, nr);
+                __syncthreads();
+                dead = dead || s_dead != 0;
+                if (tid < nr) {
+                    const float *hp = xh + tid * KX + E, *wp = wrow + dd * H;
 #pragma unroll 8
-                for (int k4 = 0; k4 < H / 4; ++k4) {
-                    const float4 w = *reinterpret_cast<const float4 *>(wp + 4 * k4);
-                    const float4 x = *reinterpret_cast<const float4 *>(hp + 4 * k4);
-                    sfc = __builtin_fmaf(x.x, w.x, sfc); sfc = __builtin_fmaf(x.y, w.y, sfc);
-                    sfc = __builtin_fmaf(x.z, w.z, sfc); sfc = __builtin_fmaf(x.w, w.w, sfc);
+                    for (int k4 = 0; k4 < H / 4; ++k4) {
+                        const float4 w = *reinterpret_cast<const float4 *>(wp + 4 * k4);
+                        const float4 x = *reinterpret_cast<const float4 *>(hp + 4 * k4);
+                        sfc = __builtin_fmaf(x.x, w.x, sfc); sfc = __builtin_fmaf(x.y, w.y, sfc);
+                        sfc = __builtin_fmaf(x.z, w.z, sfc); sfc = __builtin_fmaf(x.w, w.w, sfc);
+                    }
                 }
             }
+            if (tid < nr) a.out[(size_t)(row0 + tid) * a.D + o] = dead ? __uint_as_float(0x7fc00000u) : sfc + a.bfc[o];
         }
-        if (tid < B && tid < RB) a.out[(size_t)tid * a.D + o] = dead ? __uint_as_float(0x7fc00000u) : sfc + a.bfc[o];
     }
     if (dead && tid == 0) atomicOr(a.err, 1u);
 }
@@ -872,7 +892,7 @@ static LstmWs carve(void *base, int64_t B, int T, int E, int H, int vocab)
         w.tokidx = reinterpret_cast<int *>(take_b(R * T * sizeof(int)));
     }
     if (B <= 4) w.wt = take((size_t)2 * (E + H) * 4 * H);       // k-major weights of the vector-chain step (a few queries)
-    if (B <= 32) w.hg = reinterpret_cast<unsigned long long *>(take_b(16 + (size_t)4 * B * H * sizeof(unsigned long long)));
+    if (B <= 64) w.hg = reinterpret_cast<unsigned long long *>(take_b(16 + (size_t)4 * B * H * sizeof(unsigned long long)));
     w.total = off;
     return w;
 }
@@ -907,10 +927,11 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
     const int G = 4 * H;
 
     VFR_REQUIRE(T <= 1024, VFR_EUNSUPPORTED, "vfr_bilstm_final_f32: T=%d > 1024", T);
-    if (vfr::opt_lstm_persist() && B > vfr::opt_lstm_persist_min() && B <= 32 && E == 100 && H == 1000 && w.hg &&
+    if (vfr::opt_lstm_persist() && B > vfr::opt_lstm_persist_min() && B <= vfr::opt_lstm_persist_max() && B <= 64 && E == 100 && H == 1000 && w.hg &&
         2 * (int)vfr::cdiv(H, 8) <= vfr::device_cu_count() &&
-        (B <= 16 ? vfr::seq_lds_admitted(vfr::lstm_seq_mfma_kernel<1, 25, 275>) : vfr::seq_lds_admitted(vfr::lstm_seq_mfma_kernel<2, 25, 275>))) {
-        // 3 .. 32 queries at the model's shape: the whole sequence in one launch on the matrix pipe, weights in registers
+        (B <= 16 ? vfr::seq_lds_admitted(vfr::lstm_seq_mfma_kernel<1, 1, 25, 275>)
+                 : B <= 32 ? vfr::seq_lds_admitted(vfr::lstm_seq_mfma_kernel<2, 1, 25, 275>) : vfr::seq_lds_admitted(vfr::lstm_seq_mfma_kernel<2, 2, 25, 275>))) {
+        // 3 .. 64 queries at the model's shape: the whole sequence in one launch on the matrix pipe, weights in registers
         // (lstm_seq_mfma_kernel); every query steps through all T tokens (no sorting, no pad row)
         const size_t gbytes = 16 + (size_t)4 * B * H * sizeof(unsigned long long);
         if (hipMemsetAsync(w.hg, 0, gbytes, st) != hipSuccess)
@@ -929,8 +950,9 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
         vfr::ProfScope prof(vfr::SITE_GEMM_LSTM_REC, st);
         const int rtiles = B <= 16 ? 1 : 2;
         const size_t lds = ((size_t)16 * rtiles * (E + H + 32) + 4 + 2 * H) * sizeof(float);
-        if (rtiles == 1) hipLaunchKernelGGL((vfr::lstm_seq_mfma_kernel<1, 25, 275>), grid, dim3(256), lds, st, a);
-        else             hipLaunchKernelGGL((vfr::lstm_seq_mfma_kernel<2, 25, 275>), grid, dim3(256), lds, st, a);
+        if (rtiles == 1)  hipLaunchKernelGGL((vfr::lstm_seq_mfma_kernel<1, 1, 25, 275>), grid, dim3(256), lds, st, a);
+        else if (B <= 32) hipLaunchKernelGGL((vfr::lstm_seq_mfma_kernel<2, 1, 25, 275>), grid, dim3(256), lds, st, a);
+        else              hipLaunchKernelGGL((vfr::lstm_seq_mfma_kernel<2, 2, 25, 275>), grid, dim3(256), lds, st, a);
         }
         VFR_CHECK_LAUNCH("lstm_seq_mfma_kernel");
         if (fc_in) return VFR_OK;

@@ -30,6 +30,7 @@ int opt_lstm_tile();
 int opt_lstm_small4();
 int opt_lstm_persist();
 int opt_lstm_persist_min();
+int opt_lstm_persist_max();
 int opt_lstm_persist_fault();
 int opt_vgg_fuse_pool();
 int opt_vgg_direct1();
