@@ -70,6 +70,30 @@ for it in range(iters):
                             d(lt) if lt is not None else None).cpu().numpy()
     report("bilstm", f"B={B} T={T} E={E} H={H} vocab={vocab} D={Dq} normlen={lt is not None}", np.array_equal(got, want))
 
+    # ---- BiLSTM at the model's width (E = 100, H = 1000), 1 .. 34 queries: the single-launch sequence kernels (vector chains for
+    # one or two queries, the matrix pipe for 3 .. 32) and the tile steps just above them
+    if it % 3 == 0:
+        B = int(rs.choice([1, 2, 3, 5, 9, 16, 17, 31, 32, 34]))
+        T = int(rs.choice([1, 2, 5, 20]))
+        E, H, vocab, Dq = 100, 1000, int(rs.choice([3, 60, 400])), int(rs.choice([1, 100, 260]))
+        tokens = np.zeros((B, T), np.int64)
+        for b in range(B):
+            L = int(rs.randint(0, T + 1))
+            tokens[b, :L] = rs.randint(1, vocab, size=L)
+        emb = rs.randn(vocab, E).astype(np.float32); emb[0] = 0
+        lstm = {}
+        for suf in ("", "_reverse"):
+            lstm["weight_ih_l0" + suf] = (rs.randn(4 * H, E) * 0.05).astype(np.float32)
+            lstm["weight_hh_l0" + suf] = (rs.randn(4 * H, H) * 0.03).astype(np.float32)
+            lstm["bias_ih_l0" + suf] = (rs.randn(4 * H) * 0.1).astype(np.float32)
+            lstm["bias_hh_l0" + suf] = (rs.randn(4 * H) * 0.1).astype(np.float32)
+        Wfc = (rs.randn(Dq, 2 * H) * 0.05).astype(np.float32); bfc = rs.randn(Dq).astype(np.float32)
+        lt = (rs.rand(vocab, 1).astype(np.float32) + 0.5) if rs.randint(2) else None
+        want = oracle.bilstm_final(tokens, emb, lstm, Wfc, bfc, lt)
+        got = _vfr.bilstm_final(d(tokens), d(emb), {k: d(v) for k, v in lstm.items()}, d(Wfc), d(bfc),
+                                d(lt) if lt is not None else None).cpu().numpy()
+        report("bilstm1000", f"B={B} T={T} vocab={vocab} D={Dq} normlen={lt is not None}", np.array_equal(got, want))
+
     # ---- pooling
     Tf = int(rs.choice([1, 24, 25, 26, 150, 333]))
     Fp = int(rs.choice([4, 100, 2048, 4096]))
