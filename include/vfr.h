@@ -296,7 +296,7 @@ int vfr_math_f32(int op, const float *x, const float *y, float *out, int64_t n, 
  * launches), "lstm_tile" 0|1|2|3 (fused LSTM step tile rows: automatic | 64 | 128 | 32), "gemm_pp" 0|1 (experimental ping-pong
  * schedule of the large MFMA GEMMs, default 0), "score_pre_b" N (videos in the top-k threshold ladder's stage B; 0 = Nv/16
  * capped at 640), "score_tasks" N (wave-tasks the fused scorer's plan aims for; 0 = automatic), "lstm_skip0" 1|0 (the first LSTM step
- * skips its recurrent segment because h_0 = 0 | runs it), "score_smallq" N (vfr_score_topk_mfma, f32: batches of up to N <= 32 queries against banks of <= 21 clips per video are scored with lanes = clips / videos, the top-k by video selection, default 32; 0: always the fused kernels), "lstm_small" N (batches of up to N <= 4 queries take the vector-chain LSTM step, default 2; 0: always the MFMA tiles), "score_mfma_min" N (vfr_score_topk_mfma hands banks of fewer than N videos to the exact kernels, default 128), "gemm_small" 0|64 (GEMMs of under 384 128-row tiles: 32-row tiles |
+ * skips its recurrent segment because h_0 = 0 | runs it), "score_smallq" N (vfr_score_topk_mfma, f32: batches of up to N <= 64 queries against banks of <= 21 clips per video are scored with lanes = clips / videos, the top-k by video selection, default 64; 0: always the fused kernels), "lstm_small" N (batches of up to N <= 4 queries take the vector-chain LSTM step, default 2; 0: always the MFMA tiles), "score_mfma_min" N (vfr_score_topk_mfma hands banks of fewer than N videos to the exact kernels, default 128), "gemm_small" 0|64 (GEMMs of under 384 128-row tiles: 32-row tiles |
  * 64-row tiles), "lstm_xcd" 1|0 (XCD-aware workgroup order of the fused LSTM step | launch order), "lstm_persist" 1|0 (up to 32
  * queries: the whole BiLSTM sequence in ONE launch -- one or two queries: weight slices resident in LDS, vector chains; above
  * "lstm_persist_min" (default 2) at the model's shape: weights resident in registers as MFMA fragments -- with h handed between

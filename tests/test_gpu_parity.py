@@ -25,18 +25,26 @@ def vfr():
     return _vfr
 
 
+@pytest.fixture(autouse=True)
+def prefilter_reachable(vfr):
+    """The library scores batches of up to 64 queries with the few-queries path; most scoring tests here use such batches to
+    exercise the MFMA pre-filter and the fused kernels, so the limit is 8 for every test (the few-queries tests raise it)."""
+    old = vfr.get_option("score_smallq")
+    vfr.set_option("score_smallq", 8)
+    yield
+    vfr.set_option("score_smallq", old)
+
+
 @pytest.fixture(params=["exact", "mfma"])
 def score_mode(request, vfr):
     """Every scoring test runs twice: the exact VALU kernels, and the fp32 MFMA pre-filter + exact re-scoring path
     (vfr_score_topk_mfma, dtype f32), whose outputs must be the same bits."""
-    old, old_min, old_sq = vfr.DEFAULT_SCORE_MODE, vfr.get_option("score_mfma_min"), vfr.get_option("score_smallq")
+    old, old_min = vfr.DEFAULT_SCORE_MODE, vfr.get_option("score_mfma_min")
     vfr.DEFAULT_SCORE_MODE = request.param
     vfr.set_option("score_mfma_min", 0)              # the tests' small banks must reach the pre-filter kernels too
-    vfr.set_option("score_smallq", 8)                # ... and their 9-32-query batches (the few-queries path has its own tests)
     yield request.param
     vfr.DEFAULT_SCORE_MODE = old
     vfr.set_option("score_mfma_min", old_min)
-    vfr.set_option("score_smallq", old_sq)
 
 
 def dev(a, dtype=None):
@@ -497,12 +505,13 @@ def test_file_dataset_pools_on_gpu_and_evaluates(vfr, oracle, golden, mode, tmp_
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nq", [1, 2, 3, 5, 8, 13, 32])
+@pytest.mark.parametrize("nq", [1, 2, 3, 5, 8, 13, 32, 57])
 def test_few_queries_scoring_path(vfr, nq):
-    """1-32 queries (a serving request) are scored with lanes = clips / videos; the top-k comes from the videos whose smallest
+    """1-64 queries (a serving request) are scored with lanes = clips / videos; the top-k comes from the videos whose smallest
     clip distance can still reach it (`score_smallq_select`; off: a selection tree over the key array)
     (`score_smallq`): top-k lists and rank counts bit-identical to the fused kernels (option off) and to dense + stable sort;
     ragged clip counts, an empty video, duplicated videos (exact ties), k = 0 / 1 / 100 / more than there are moments, 1-4 rank keys."""
+    vfr.set_option("score_smallq", 64)             # (the library's default; the module's fixture lowers it for the other tests)
     rs = np.random.RandomState(40 + nq)
     for case in range(3):
         nv = [1, 37, 700][case]
@@ -526,11 +535,11 @@ def test_few_queries_scoring_path(vfr, nq):
             try:
                 vfr.set_option("score_smallq", 0)
                 d2, i2, c2 = vfr.score_topk(Q, bank, k, rd, ri, mode="mfma")
-                vfr.set_option("score_smallq", 32)
+                vfr.set_option("score_smallq", 64)
                 vfr.set_option("score_smallq_select", 0)       # the key array + selection tree instead of the video selection
                 d3, i3, c3 = vfr.score_topk(Q, bank, k, rd, ri, mode="mfma")
             finally:
-                vfr.set_option("score_smallq", 32)
+                vfr.set_option("score_smallq", 64)
                 vfr.set_option("score_smallq_select", 1)
             assert c.tolist() == [[p] * nq for p in pos] and torch.equal(c, c2) and torch.equal(c, c3)
             if k:

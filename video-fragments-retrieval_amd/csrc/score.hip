@@ -1855,7 +1855,7 @@ __global__ __launch_bounds__(SQS_THREADS) void smallq_select_kernel(const float 
     }
 }
 
-constexpr int SMALLQ_MAX = 32, SMALLQ_CLIPS = SMALLQ_CLIPS_MAX;
+constexpr int SMALLQ_MAX = 64, SMALLQ_CLIPS = SMALLQ_CLIPS_MAX;
 struct SmallqWs { float *dist; unsigned long long *keys, *bufa, *bufb; float *dmin; int64_t Mpad, P0, P1; size_t total; };
 constexpr int SQ_F1 = 20, SQ_F = 32;        // lists of k per first-level range; fan-in of the later levels
 static SmallqWs carve_smallq(void *base, int64_t Nq, int total_clips, int k)

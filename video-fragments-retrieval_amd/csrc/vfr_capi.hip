@@ -18,7 +18,7 @@ static std::atomic<int> g_opt_gemm_small{0};       // small dense GEMMs: 0 = 32-
 static std::atomic<int> g_opt_lstm_xcd{1};         // 1: XCD-aware workgroup order of the fused LSTM step; 0: launch order (cross-check)
 static std::atomic<int> g_opt_lstm_skip0{1};       // 1: the first LSTM step skips its recurrent segment (h_0 = 0); 0: runs it (cross-check)
 static std::atomic<int> g_opt_score_tasks{0};      // > 0: wave-tasks the scorer's plan aims for (experiment; 0 = automatic)
-static std::atomic<int> g_opt_score_smallq{32};    // batches of up to this many queries (<= 32) are scored with lanes = clips / videos (vfr_score_topk_mfma, f32); 0: never
+static std::atomic<int> g_opt_score_smallq{64};    // batches of up to this many queries (<= 64) are scored with lanes = clips / videos (vfr_score_topk_mfma, f32); 0: never
 static std::atomic<int> g_opt_score_pre_b{0};      // > 0: videos in ladder stage B (experiment; 0 = Nv/16 capped at 640)
 static std::atomic<int> g_opt_gemm_pp{0};          // 1: ping-pong schedule (512-thread workgroups, two tile groups) for the large MFMA GEMMs (experiment)
 static std::atomic<int> g_opt_mfma_min{128};        // banks of fewer videos go to the exact scorer (the pre-filter's fixed launches cost more); tests set 0
