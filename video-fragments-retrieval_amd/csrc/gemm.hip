@@ -111,6 +111,9 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
 #ifndef VFR_GEMM_SETPRIO
 #define VFR_GEMM_SETPRIO 0
 #endif
+#ifndef VFR_GEMM_SPREAD
+#define VFR_GEMM_SPREAD 2    // 2: staging stores interleaved 1:1 with the MFMAs of slices 1-2, order pinned (see the K-tile loop); 1: interleaved, order left to the scheduler; 0: one block behind slice 1
+#endif
 #ifndef VFR_GEMM_DEEP
 #define VFR_GEMM_DEEP 0      // 1: two staging register sets, K-tiles kt + 2 and kt + 3 in flight (see DEEP in the kernel body); 0: one.
                              // EXPERIMENT (round 3): bit-identical, +20..32 VGPRs, and no faster anywhere -- the fused LSTM step at 64 / 200 /
@@ -547,6 +550,20 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             *reinterpret_cast<float4 *>(&Ws[lds_off(row, kk)]) = v;
         }
     };
+    // one staged float4 (piece j < NA: of A, else of W) -> LDS: the pieces of swrite, for the interleaved schedule
+    auto swrite_piece = [&](int b, auto sc, int j) {
+        constexpr int S = decltype(sc)::value;
+        float *As = lds + b * BUF_FLOATS, *Ws = As + A_FLOATS;
+        if (j < NA) {
+            const int f = tid + 256 * j, row = f >> 3, kk = (f & 7) * 4;
+            float4 v = ra[S][j];
+            if (CONV || LSTM) { const bool z = za[S][j]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
+            *reinterpret_cast<float4 *>(&As[lds_off(row, kk)]) = v;
+        } else {
+            const int i = j - NA, f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
+            *reinterpret_cast<float4 *>(&Ws[lds_off(row, kk)]) = rw[S][i];
+        }
+    };
     auto compute = [&](int b) {
         const float *As = lds + b * BUF_FLOATS, *Ws = As + A_FLOATS;
         // fragment of tile row block ti at k-slice k4: ONE dword per lane, A[16*ti + (lane & 15)][4*k4 + (lane >> 4)] -- exactly
@@ -668,15 +685,40 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 if (sn < NS) frag_read(cb, sn, sn % RING);
                 else         frag_read(nb, sn - NS, sn % RING);    // (past the last K-tile: stale data, never used)
                 __builtin_amdgcn_sched_barrier(0);
+                // VFR_GEMM_SPREAD: the staging stores of K-tile kt + 1 go out ONE behind each MFMA of slices 1 and 2 instead of as a
+                // block behind slice 1 (a wave alone on its SIMD issues no MFMA while it moves 5-8 float4 to the LDS: 254 cycles
+                // per K-tile of a 32-row tile)
+                constexpr int NM = TI * 4, NPIECE = NA + NW;
+                static_assert(!VFR_GEMM_SPREAD || NPIECE <= 2 * NM, "staging pieces must fit behind the MFMAs of two slices");
 #pragma unroll
                 for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-                    for (int tj = 0; tj < 4; ++tj)
+                    for (int tj = 0; tj < 4; ++tj) {
                         acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[k4 % RING][ti], fb[k4 % RING][tj], acc[ti][tj], 0, 0, 0);
+                        if (VFR_GEMM_SPREAD && (k4 == 1 || k4 == 2)) {
+                            const int piece = (k4 - 1) * NM + ti * 4 + tj;
+                            if (piece < NPIECE) swrite_piece(nb, std::integral_constant<int, DEEP ? nb : 0>{}, piece);
+                        }
+                    }
+#if VFR_GEMM_SPREAD == 2
+                // (pin the order: MFMA, [the piece's zero-selects], its LDS store -- left alone the scheduler hangs four of the stores
+                // behind the first MFMA)
+                if (k4 == 1 || k4 == 2) {
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        const int piece = (k4 - 1) * NM + m;
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (piece < NPIECE) {
+                            if ((CONV || LSTM) && piece < NA) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        }
+                    }
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 // DEEP: K-tile kt + 1 sits in register set nb (= its parity); once it is in LDS that set takes K-tile kt + 3,
                 // while set cb still holds K-tile kt + 2 in flight
-                if (k4 == 1) swrite(nb, std::integral_constant<int, DEEP ? nb : 0>{});
+                if (!VFR_GEMM_SPREAD && k4 == 1) swrite(nb, std::integral_constant<int, DEEP ? nb : 0>{});
                 if (k4 == VFR_GLOAD_SLICE) {
                     const int ahead = DEEP ? 3 : 2;
                     const int t2 = kt + ahead < nk ? kt + ahead : nk - 1;
