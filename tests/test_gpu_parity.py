@@ -729,6 +729,30 @@ def test_sequence_kernels_give_up_loudly_when_a_workgroup_is_missing(vfr, B):
 
 
 @pytest.mark.gpu
+def test_bilstm_select_free_step_agrees(vfr, oracle):
+    """The table-start LSTM step has an instantiation without selects in its K-loop (`lstm_fast`: one segment of whole K-tiles,
+    the remainder as direct fragments), picked when the launch qualifies (H = 1000: 31 tiles + 8; H = 96: 3 tiles): same bits as
+    the general form and as the oracle, 32- and 64-row tiles, a batch with all-pad and short queries."""
+    for H, B in ((1000, 300), (1000, 900), (96, 130)):
+        sd = synth.model_weights(4096, seed=21, hidden=H)
+        tokens = synth.query_tokens(B, seed=21)
+        tokens[3, :] = 0
+        args = (dev(tokens), dev(sd["word_embedding.weight"]), {k: dev(v) for k, v in lstm_of(sd).items()},
+                dev(sd["lang_fc.weight"]), dev(sd["lang_fc.bias"]))
+        fast = vfr.bilstm_final(*args)
+        try:
+            vfr.set_option("lstm_fast", 0)
+            general = vfr.bilstm_final(*args)
+        finally:
+            vfr.set_option("lstm_fast", 1)
+        assert torch.equal(fast.view(torch.int32), general.view(torch.int32)), (H, B)
+        n = 40
+        want = oracle.bilstm_final(tokens[:n], sd["word_embedding.weight"], lstm_of(sd), sd["lang_fc.weight"], sd["lang_fc.bias"])
+        sub = vfr.bilstm_final(dev(tokens[:n]), *args[1:])
+        assert same(sub, want), (H, B)
+
+
+@pytest.mark.gpu
 def test_bilstm_tile_shapes_agree(vfr, oracle):
     """The fused LSTM step picks 32-, 64- or 128-row tiles by batch size; all are the same chains.  Forced either way on one
     batch: identical bits to each other and (on the rows the oracle is run for) to the oracle."""

@@ -163,10 +163,15 @@ __device__ unsigned long long g_gemm_stamps[4];
 // work on that stall.
 // NARROW = 64-column workgroup tile, the four waves stacked along M (each wave still 16*TI x 64): for operands with N <= 64
 // (VGG conv1_1 / conv1_2), where the 128-column tile would spend half of every MFMA on columns that do not exist.
-template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false, bool NARROW = false, bool TRAIN = false, bool CFAST = false>
+// LFAST = the fused LSTM step in the shape the bench and the model run it: chains start from the projection table (K == 0: one
+// segment) and the recurrent segment is whole K-tiles (+ a remainder of <= 8 taken as direct fragments) -- no segment select
+// per staging load, no zero-fill select per staged A chunk: no vector ALU instruction left in the K-loop (14 v_cndmask per 64
+// MFMAs in the general form, and VALU time is matrix-pipe time).  lstm_step_pair picks it when the launch qualifies.
+template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false, bool NARROW = false, bool TRAIN = false, bool CFAST = false, bool LFAST = false>
 __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
     static_assert(!CFAST || CONV, "CFAST: the convolution loader for C_in a multiple of 32");
+    static_assert(!LFAST || (LSTM && !PP), "LFAST: the table-start LSTM step");
     static_assert(!TRAIN || LSTM, "TRAIN: the fused LSTM step that also stores its gates");
     static_assert(!NARROW || (MI == 1 && !LSTM && !PP), "narrow tile: 128 x 64 only");
     constexpr int TBM = NARROW ? 128 * MI : (MI ? 64 * MI : 32);    // tile rows (MI = 0: the 32-row tile, one row tile per wave)
@@ -467,6 +472,15 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     bool zq = false;
     auto gload_seg = [&](int k0t, auto sc) {
         constexpr int S = decltype(sc)::value;
+        if constexpr (LFAST) {           // one segment of whole K-tiles: scalar base + the thread's fixed offsets, nothing to select
+            const char *ba = reinterpret_cast<const char *>(g.A2 + k0t);
+            const char *bw = reinterpret_cast<const char *>(g.W2 + k0t);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { asm volatile("" : "+v"(aoff2[i])); ra[S][i] = *reinterpret_cast<const float4 *>(ba + aoff2[i]); }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) { asm volatile("" : "+v"(woff2[i])); rw[S][i] = *reinterpret_cast<const float4 *>(bw + woff2[i]); }
+            return;
+        }
         const int kt = k0t / MBK;
         const bool second = kt >= nk1;
         const int Kseg = second ? g.K2 : g.K, kseg = (second ? kt - nk1 : kt) * MBK;
@@ -538,7 +552,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         for (int i = 0; i < NA; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
             float4 v = ra[S][i];
-            if (CONV || LSTM) { const bool z = za[S][i]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
+            if (CONV || (LSTM && !LFAST)) { const bool z = za[S][i]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
             *reinterpret_cast<float4 *>(&As[lds_off(row, kk)]) = v;
         }
 #pragma unroll
@@ -557,7 +571,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         if (j < NA) {
             const int f = tid + 256 * j, row = f >> 3, kk = (f & 7) * 4;
             float4 v = ra[S][j];
-            if (CONV || LSTM) { const bool z = za[S][j]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
+            if (CONV || (LSTM && !LFAST)) { const bool z = za[S][j]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
             *reinterpret_cast<float4 *>(&As[lds_off(row, kk)]) = v;
         } else {
             const int i = j - NA, f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
@@ -709,7 +723,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                         const int piece = (k4 - 1) * NM + m;
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         if (piece < NPIECE) {
-                            if ((CONV || LSTM) && piece < NA) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                            if ((CONV || (LSTM && !LFAST)) && piece < NA) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                         }
                     }
@@ -900,11 +914,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp)
 template <int MI = 2, bool NARROW = false, bool CFAST = false>
 __global__ __launch_bounds__(256, MI <= 1 ? 3 : 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true, false, MI, false, NARROW, false, CFAST>(g); }
 
-template <int MI>
+template <int MI, bool LFAST = false>
 __global__ __launch_bounds__(256, MI <= 1 ? 3 : VFR_LSTM_WAVES) void lstm_step_mfma_pair(GemmPair gp)
 {
     const GemmArgs g = gp.p[blockIdx.z];      // private copy, see gemm_nt_mfma_pair
-    gemm_nt_mfma_body<true, false, true, MI>(g);
+    gemm_nt_mfma_body<true, false, true, MI, false, false, false, false, LFAST>(g);
 }
 template <int MI>
 __global__ __launch_bounds__(256, MI <= 1 ? 3 : 2) void lstm_step_train_mfma_pair(GemmPair gp)
@@ -1007,14 +1021,23 @@ int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
         const unsigned rt = (unsigned)cdiv(g0.M, rows);
         return xcd ? dim3(rt * (unsigned)cpx * 8u, 1, 2) : dim3(rt, (unsigned)ncol, 2);
     };
+    // the table-start step with a recurrent segment of whole K-tiles (+ a remainder the kernel takes as direct fragments): the
+    // instantiation without selects in its K-loop (same chains)
+    auto fast_ok = [&](const GemmArgs &g) {
+        const int rem = g.K2 % MBK;
+        return g.lstm_tok && g.K == 0 && g.K2 >= MBK && (rem == 0 || (g.K2 > MBK && rem <= 8));
+    };
+    const bool lfast = opt_lstm_fast() && fast_ok(g0) && fast_ok(g1) && VFR_GEMM_PIPE && VFR_LSTM_NBUF == 2;
     if (g0.lstm_gates) {                     // training forward: the same step, gates stored as well (32- or 64-row tiles)
         VFR_REQUIRE(g1.lstm_gates, VFR_EINVAL, "lstm_step_pair: gates buffer for one direction only");
         if (tile == 3) hipLaunchKernelGGL(lstm_step_train_mfma_pair<0>, grid_for(32), dim3(256), 0, st, gp);
         else           hipLaunchKernelGGL(lstm_step_train_mfma_pair<1>, grid_for(64), dim3(256), 0, st, gp);
     } else if (tile == 3) {                  // 32-row tiles, three workgroups per CU
-        hipLaunchKernelGGL(lstm_step_mfma_pair<0>, grid_for(32), dim3(256), 0, st, gp);
+        if (lfast) hipLaunchKernelGGL((lstm_step_mfma_pair<0, true>), grid_for(32), dim3(256), 0, st, gp);
+        else       hipLaunchKernelGGL(lstm_step_mfma_pair<0>, grid_for(32), dim3(256), 0, st, gp);
     } else if (tile != 2) {
-        hipLaunchKernelGGL(lstm_step_mfma_pair<1>, grid_for(64), dim3(256), 0, st, gp);
+        if (lfast) hipLaunchKernelGGL((lstm_step_mfma_pair<1, true>), grid_for(64), dim3(256), 0, st, gp);
+        else       hipLaunchKernelGGL(lstm_step_mfma_pair<1>, grid_for(64), dim3(256), 0, st, gp);
     } else if (opt_gemm_pp()) {
         dim3 grid((unsigned)cdiv(cdiv(g0.M, MBM), 2), (unsigned)cdiv(g0.lstm_H, 32), 2);
         hipLaunchKernelGGL(lstm_step_mfma_pair_pp, grid, dim3(512), 0, st, gp);

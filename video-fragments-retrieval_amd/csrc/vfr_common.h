@@ -29,6 +29,7 @@ int opt_gemm_small();
 int opt_lstm_tile();
 int opt_lstm_small4();
 int opt_lstm_persist();
+int opt_lstm_fast();
 int opt_lstm_persist_min();
 int opt_lstm_persist_max();
 int opt_lstm_persist_fault();
