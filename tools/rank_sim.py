@@ -125,7 +125,7 @@ for _ in range(reps):
     step()
 torch.cuda.synchronize()
 sites = _vfr.profile_read(reset=True); _vfr.set_option("profile", 0)
-ONE = float(__import__("os").environ.get("VFR_ONE_GPU_MS", "24.60"))      # measured 1-GPU step (profiles/r3a_bench_unprofiled.json)
+ONE = float(__import__("os").environ.get("VFR_ONE_GPU_MS", "23.62"))      # measured 1-GPU step (profiles/r3f_bench_unprofiled.json)
 print(f"N={N}: rank-0 step without wire time {ms:.3f} ms   (1-GPU step {ONE} ms / N = {ONE / N:.3f} ms)  -> speed-up bound {ONE / ms:.2f}x")
 for name, v in marks.items():
     print(f"  {name:16s} {min(v):7.3f} ms (synchronised)")
