@@ -374,6 +374,25 @@ def test_vgg_conv_launch_forms_bit_exact(vfr, oracle, cfg, T):
     assert torch.equal(got.view(torch.int32), unfused.view(torch.int32))
 
 
+@pytest.mark.parametrize("hw,T", [((32, 32), 5), ((48, 40), 3)])
+def test_vgg_halo_padded_stack_bit_exact(vfr, oracle, hw, T):
+    """Widths that are multiples of 32 and even sizes at every pool: the stack runs on halo-padded activations (`vgg_halo`:
+    zero border, convolution loader without tap masks or selects, pooled outputs written into the next padded tensor) -- ==
+    the oracle and == the unpadded stack (option off), bit for bit; 128 x 64 and 64-row launch forms, a tile that spans images."""
+    cfg = [32, 32, "M", 64, 64, "M", 160, 32, "M"]
+    frames = synth.frames_u8(T, hw[0], hw[1], seed=12)
+    cw, cb, fc6, fc7 = synth.vgg_weights(cfg, hw, 64, seed=12)
+    args = (dev(frames), cfg, [dev(w) for w in cw], [dev(b) for b in cb], (dev(fc6[0]), dev(fc6[1])), (dev(fc7[0]), dev(fc7[1])))
+    got = vfr.vgg_fc7(*args)
+    assert same(got, oracle.vgg_fc7(frames, cw, cb, fc6, fc7, cfg))
+    try:
+        vfr.set_option("vgg_halo", 0)
+        plain = vfr.vgg_fc7(*args)
+    finally:
+        vfr.set_option("vgg_halo", 1)
+    assert torch.equal(got.view(torch.int32), plain.view(torch.int32))
+
+
 def test_vgg_first_conv_direct_kernel_ragged(vfr, oracle):
     """The direct first-convolution kernel's 16-channel rounds (LDS-transposed stores) on a pixel count that is no multiple of
     a wave, a pool on an odd height behind it (not fusable) and fused ones elsewhere: == oracle."""

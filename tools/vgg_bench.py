@@ -11,6 +11,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import vfr_amd  # noqa
 from vfr_amd import _vfr, synth
+for _item in filter(None, __import__("os").environ.get("VFR_OPTS", "").split(",")):     # e.g. VFR_OPTS=vgg_halo=0
+    _vfr.set_option(_item.split("=")[0], int(_item.split("=")[1]))
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2

@@ -167,10 +167,15 @@ __device__ unsigned long long g_gemm_stamps[4];
 // segment) and the recurrent segment is whole K-tiles (+ a remainder of <= 8 taken as direct fragments) -- no segment select
 // per staging load, no zero-fill select per staged A chunk: no vector ALU instruction left in the K-loop (14 v_cndmask per 64
 // MFMAs in the general form, and VALU time is matrix-pipe time).  lstm_step_pair picks it when the launch qualifies.
-template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false, bool NARROW = false, bool TRAIN = false, bool CFAST = false, bool LFAST = false>
+// CHALO = the scalar-tap convolution loader on HALO-PADDED activations: input [B][H + 2][W + 2][C_in] with a zero border, output
+// written into the interior of a tensor padded the same way (pooled size under EPI_POOL2).  Every tap of every output pixel then
+// reads real memory holding the right value -- zero outside the image -- so the loader needs no tap mask, no address select and
+// no zero-fill select: like the dense loop, no vector ALU instruction per K-tile (32 per 128 MFMAs in the masked form).
+template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false, bool NARROW = false, bool TRAIN = false, bool CFAST = false, bool LFAST = false, bool CHALO = false>
 __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 {
     static_assert(!CFAST || CONV, "CFAST: the convolution loader for C_in a multiple of 32");
+    static_assert(!CHALO || CFAST, "CHALO: the scalar-tap loader on halo-padded activations");
     static_assert(!LFAST || (LSTM && !PP), "LFAST: the table-start LSTM step");
     static_assert(!TRAIN || LSTM, "TRAIN: the fused LSTM step that also stores its gates");
     static_assert(!NARROW || (MI == 1 && !LSTM && !PP), "narrow tile: 128 x 64 only");
@@ -192,6 +197,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // double-buffered tiles: [2][A | W] -> two (padded 128-row tiles) or three workgroups per CU
     constexpr int NBUF = PP ? 1 : (LSTM ? VFR_LSTM_NBUF : VFR_GEMM_NBUF);
     __shared__ __attribute__((aligned(16))) float lds_all[(PP ? 2 : 1) * NBUF * BUF_FLOATS];
+    __shared__ int otab_s[CHALO ? TBM : 1];              // CHALO: padded output pixel of every tile row (pooled pixel under EPI_POOL2)
     const int grp = PP ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // tile group of this wave
     float *lds = lds_all + grp * NBUF * BUF_FLOATS;
     const int tid = PP ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -404,6 +410,12 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     };
     int64_t clin0 = m0;                                                 // linear pixel index of the tile's first row
     if (CONV && cpool) { int n0_, y0_, x0_; clin0 = conv_pixel(m0 < g.M ? m0 : 0, n0_, y0_, x0_); }
+    int64_t chalo0 = 0;                                                 // CHALO: padded index of the tile's first pixel
+    if constexpr (CHALO) {
+        int n0_, y0_, x0_;
+        (void)conv_pixel(m0 < g.M ? m0 : 0, n0_, y0_, x0_);
+        chalo0 = ((int64_t)n0_ * (g.conv_h + 2) + y0_ + 1) * (g.conv_w + 2) + x0_ + 1;
+    }
     if (CONV) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -412,6 +424,17 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             crow_ok[i] = p < g.M;
             const int64_t pc = crow_ok[i] ? p : 0;
             const int64_t plin = conv_pixel(pc, cn[i], coy[i], cox[i]);
+            if constexpr (CHALO) {
+                const int wp = g.conv_w + 2;
+                const int64_t pin = ((int64_t)cn[i] * (g.conv_h + 2) + coy[i] + 1) * wp + cox[i] + 1;     // padded centre pixel
+                coffb[i] = (unsigned)(((crow_ok[i] ? pin - chalo0 : 0) * g.conv_cin + (f & 7) * 4) * 4);
+                ctap[i] = 0;
+                if ((f & 7) == 0) {
+                    const int oh = cpool ? (g.conv_h >> 1) : g.conv_h, ow = cpool ? (g.conv_w >> 1) : g.conv_w;
+                    const int oy = cpool ? (coy[i] >> 1) : coy[i], ox = cpool ? (cox[i] >> 1) : cox[i];
+                    otab_s[row] = (int)(((int64_t)cn[i] * (oh + 2) + oy + 1) * (ow + 2) + ox + 1);
+                }
+            } else
             if (CFAST) {
                 unsigned mask = 0;
 #pragma unroll
@@ -429,6 +452,16 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         constexpr int S = decltype(sc)::value;
         const int kt = k0 / MBK, tap = kt / ctpt, ci0 = (kt - tap * ctpt) * MBK;
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;             // tap / 3 for tap < 9
+        if constexpr (CHALO) {
+            const int dp = (ky - 1) * (g.conv_w + 2) + (kx - 1);
+            const char *ba = reinterpret_cast<const char *>(g.A + ((chalo0 + dp) * g.conv_cin + ci0));
+            const char *bw = reinterpret_cast<const char *>(g.W + (int64_t)n0 * g.ldw + k0);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { asm volatile("" : "+v"(coffb[i])); ra[S][i] = *reinterpret_cast<const float4 *>(ba + coffb[i]); }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) { asm volatile("" : "+v"(woff1[i])); rw[S][i] = *reinterpret_cast<const float4 *>(bw + woff1[i]); }
+            return;
+        }
         const int dpix = (ky - 1) * g.conv_w + (kx - 1);
         const unsigned dbytes = (unsigned)(dpix * g.conv_cin * 4), tbit = 1u << tap;
         // (m0 + dpix) * C_in + ci0 - bias may lie before the tensor: only ever dereferenced with an in-image offset added
@@ -552,7 +585,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         for (int i = 0; i < NA; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
             float4 v = ra[S][i];
-            if (CONV || (LSTM && !LFAST)) { const bool z = za[S][i]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
+            if ((CONV && !CHALO) || (LSTM && !LFAST)) { const bool z = za[S][i]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
             *reinterpret_cast<float4 *>(&As[lds_off(row, kk)]) = v;
         }
 #pragma unroll
@@ -571,7 +604,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         if (j < NA) {
             const int f = tid + 256 * j, row = f >> 3, kk = (f & 7) * 4;
             float4 v = ra[S][j];
-            if (CONV || (LSTM && !LFAST)) { const bool z = za[S][j]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
+            if ((CONV && !CHALO) || (LSTM && !LFAST)) { const bool z = za[S][j]; v.x = z ? 0.f : v.x; v.y = z ? 0.f : v.y; v.z = z ? 0.f : v.z; v.w = z ? 0.f : v.w; }
             *reinterpret_cast<float4 *>(&As[lds_off(row, kk)]) = v;
         } else {
             const int i = j - NA, f = tid + 256 * i, row = f >> 3, kk = (f & 7) * 4;
@@ -723,7 +756,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                         const int piece = (k4 - 1) * NM + m;
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         if (piece < NPIECE) {
-                            if ((CONV || (LSTM && !LFAST)) && piece < NA) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                            if (((CONV && !CHALO) || (LSTM && !LFAST)) && piece < NA) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                         }
                     }
@@ -854,7 +887,8 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 #pragma unroll
                 for (int r = 1; r < 4; ++r) { const float x = acc[ti][tj][r] + badd; v = x > v ? x : v; }
                 if (g.epi & EPI_RELU) v = v > 0.0f ? v : 0.0f;
-                g.out[(row >> 2) * g.ldo + col] = v;
+                if constexpr (CHALO) g.out[(int64_t)otab_s[row - m0] * g.ldo + col] = v;
+                else                 g.out[(row >> 2) * g.ldo + col] = v;
             }
         return;
     }
@@ -896,7 +930,8 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
                 if (g.epi & (EPI_BIAS | EPI_BIAS2)) v = v + badd;
                 if (g.epi & EPI_RES) v = v + g.res[row * g.ldr + col];
                 if (g.epi & EPI_RELU) v = v > 0.0f ? v : 0.0f;
-                g.out[row * g.ldo + col] = v;
+                if constexpr (CHALO) g.out[(int64_t)otab_s[row - m0] * g.ldo + col] = v;
+                else                 g.out[row * g.ldo + col] = v;
             }
         }
 }
@@ -911,8 +946,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp)
     gemm_nt_mfma_body<VEC, false>(g);         // kernarg array there (an s_load + lgkmcnt(0) would also drain the LDS reads)
 }
 
-template <int MI = 2, bool NARROW = false, bool CFAST = false>
-__global__ __launch_bounds__(256, MI <= 1 ? 3 : 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true, false, MI, false, NARROW, false, CFAST>(g); }
+template <int MI = 2, bool NARROW = false, bool CFAST = false, bool CHALO = false>
+__global__ __launch_bounds__(256, MI <= 1 ? 3 : 2) void conv3x3_nhwc_mfma(GemmArgs g) { gemm_nt_mfma_body<true, true, false, MI, false, NARROW, false, CFAST, false, CHALO>(g); }
 
 template <int MI, bool LFAST = false>
 __global__ __launch_bounds__(256, MI <= 1 ? 3 : VFR_LSTM_WAVES) void lstm_step_mfma_pair(GemmPair gp)
@@ -1115,9 +1150,11 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
         // (the offsets of a tile's rows from its first pixel: 128 consecutive pixels, or with the fused pool 32 windows that may
         // wrap over window rows -- under 2 * 128 + 4 * w pixels)
         const bool cf = (g.conv_cin % MBK) == 0 && (int64_t)(g.conv_w + 1 + 2 * MBM + 4 * g.conv_w + 2 * g.conv_w + 2) * g.conv_cin * 4 < (1ll << 31);
+        VFR_REQUIRE(!g.conv_halo || (cf && !(g.epi & EPI_RES)), VFR_EINVAL, "gemm_nt(conv): halo-padded activations need C_in %% 32 == 0 (and no residual)");
 #define VFR_CONV(MI_, NARROW_, GRID_, ARGS_)                                                                            \
         do {                                                                                                            \
-            if (cf) hipLaunchKernelGGL((conv3x3_nhwc_mfma<MI_, NARROW_, true>), GRID_, dim3(256), 0, st, ARGS_);         \
+            if (g.conv_halo) hipLaunchKernelGGL((conv3x3_nhwc_mfma<MI_, NARROW_, true, true>), GRID_, dim3(256), 0, st, ARGS_); \
+            else if (cf) hipLaunchKernelGGL((conv3x3_nhwc_mfma<MI_, NARROW_, true>), GRID_, dim3(256), 0, st, ARGS_);    \
             else    hipLaunchKernelGGL((conv3x3_nhwc_mfma<MI_, NARROW_, false>), GRID_, dim3(256), 0, st, ARGS_);        \
         } while (0)
         if (g.N <= 64) {                                      // conv1_x: 128 x 64 tiles, no MFMA spent on absent columns

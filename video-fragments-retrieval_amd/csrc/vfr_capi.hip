@@ -31,6 +31,7 @@ static std::atomic<int> g_opt_lstm_persist_min{2}; // batches ABOVE this many qu
 static std::atomic<int> g_opt_lstm_persist_fault{-1}; // TEST HOOK: workgroup of the single-launch sequence kernels that withholds its h of step 1 (-1: none)
 static std::atomic<int> g_opt_lstm_persist_max{32}; // ... and up to this many.  33 .. 64 are possible (two parts of <= 32 queries taking turns on the same resident weights): bit-identical, but 0.70 ms per 64-query pass against 0.62 for the tile steps (the two-part kernel's 275 weight registers + two parts' state spill): off by default
 static std::atomic<int> g_opt_lstm_fast{1};        // 1: the table-start LSTM step without selects in its K-loop where the launch qualifies; 0: always the general form (cross-check)
+static std::atomic<int> g_opt_vgg_halo{1};         // 1: the VGG stack on halo-padded activations where its shape allows (select-free convolution loader); 0: unpadded (cross-check)
 static std::atomic<int> g_opt_lstm_small4{1};      // 1: a single query of the model's shape takes the four-wave vector-chain step (weights streamed by three loader waves); 0: the one-wave step (cross-check)
 static std::atomic<int> g_opt_lstm_tile{0};        // 0: by grid size, 1: 64-row tiles, 2: 128-row tiles (fused LSTM step)
 
@@ -38,7 +39,7 @@ struct Opt { const char *name; std::atomic<int> *v; };
 static const Opt g_opts[] = {
     {"gemm", &g_opt_gemm}, {"profile", &g_opt_profile}, {"score_fast", &g_opt_score_fast}, {"score_split", &g_opt_score_split},
     {"score_pre_b", &g_opt_score_pre_b}, {"score_smallq", &g_opt_score_smallq}, {"score_tasks", &g_opt_score_tasks}, {"lstm_skip0", &g_opt_lstm_skip0},
-    {"lstm_xcd", &g_opt_lstm_xcd}, {"gemm_small", &g_opt_gemm_small}, {"lstm_tile", &g_opt_lstm_tile}, {"lstm_small4", &g_opt_lstm_small4}, {"lstm_persist", &g_opt_lstm_persist}, {"lstm_persist_min", &g_opt_lstm_persist_min}, {"lstm_fast", &g_opt_lstm_fast}, {"lstm_persist_max", &g_opt_lstm_persist_max}, {"lstm_persist_fault", &g_opt_lstm_persist_fault}, {"vgg_fuse_pool", &g_opt_vgg_fuse_pool}, {"vgg_direct1", &g_opt_vgg_direct1}, {"score_smallq_select", &g_opt_smallq_select}, {"gemm_pp", &g_opt_gemm_pp}, {"score_mfma_min", &g_opt_mfma_min}, {"lstm_small", &g_opt_lstm_small},
+    {"lstm_xcd", &g_opt_lstm_xcd}, {"gemm_small", &g_opt_gemm_small}, {"lstm_tile", &g_opt_lstm_tile}, {"lstm_small4", &g_opt_lstm_small4}, {"lstm_persist", &g_opt_lstm_persist}, {"lstm_persist_min", &g_opt_lstm_persist_min}, {"lstm_fast", &g_opt_lstm_fast}, {"lstm_persist_max", &g_opt_lstm_persist_max}, {"lstm_persist_fault", &g_opt_lstm_persist_fault}, {"vgg_fuse_pool", &g_opt_vgg_fuse_pool}, {"vgg_direct1", &g_opt_vgg_direct1}, {"vgg_halo", &g_opt_vgg_halo}, {"score_smallq_select", &g_opt_smallq_select}, {"gemm_pp", &g_opt_gemm_pp}, {"score_mfma_min", &g_opt_mfma_min}, {"lstm_small", &g_opt_lstm_small},
 };
 
 struct ProfPair { int site; hipEvent_t a, b; };
@@ -102,6 +103,7 @@ int opt_lstm_persist_max() { return g_opt_lstm_persist_max; }
 int opt_lstm_persist_fault() { return g_opt_lstm_persist_fault; }
 int opt_vgg_fuse_pool() { return g_opt_vgg_fuse_pool; }
 int opt_vgg_direct1() { return g_opt_vgg_direct1; }
+int opt_vgg_halo() { return g_opt_vgg_halo; }
 int opt_score_smallq_select() { return g_opt_smallq_select; }
 int device_cu_count()
 {

@@ -35,6 +35,7 @@ int opt_lstm_persist_max();
 int opt_lstm_persist_fault();
 int opt_vgg_fuse_pool();
 int opt_vgg_direct1();
+int opt_vgg_halo();
 int device_cu_count();
 int opt_lstm_small();
 int opt_gemm_pp();
@@ -111,6 +112,9 @@ struct GemmArgs {
     // output pixel (n, oy, ox), column k = (ky*3 + kx)*conv_cin + ci reads x[n][oy+ky-1][ox+kx-1][ci] (0 outside).
     // M = B*conv_h*conv_w, K = 9*conv_cin (conv_cin % 4 == 0), out [M, N] is the NHWC output.
     int conv_h, conv_w, conv_cin;
+    // conv_halo != 0 (conv_cin % 32 == 0): A is [B][conv_h + 2][conv_w + 2][conv_cin] with a zero border and `out` is written into the
+    // interior of a tensor padded the same way ([B][oh + 2][ow + 2][N]; oh x ow = the pooled size under EPI_POOL2)
+    int conv_halo;
     // fused LSTM step (lstm_H > 0): K is segmented, A row = [A (K cols) | A2 (K2 cols)], W row = [W | W2]; the 128 tile
     // columns are 32 hidden units x 4 gates (permuted so one lane pair holds i,f,g,o of a unit); the epilogue adds
     // bias + bias2, applies the gate nonlinearities and writes c (in place) and h_out -- no gates array.

@@ -147,11 +147,18 @@ __global__ __launch_bounds__(256) void conv_c4_weight_quad_kernel(const float *_
 // T16: Cout a multiple of 16 -- 16 channels per round, handed through a wave-private LDS tile so that a store instruction writes
 // 16 pixels x 64 contiguous bytes (4 lanes per pixel) instead of 64 pixels x 16 bytes a 256-byte stride apart (the output is
 // 1.9 GB per 150-frame video: partial-line writes were the whole cost of the first version).
+// halo != 0: the output goes into the interior of a [B][H + 2][W + 2][Cout] tensor (the halo-padded stack: gemm.hip CHALO).
 template <bool T16>
 __global__ __launch_bounds__(256) void conv3x3_c4_direct_kernel(const float4 *__restrict__ x, int64_t pixels, int H, int W,
                                                                 const float4 *__restrict__ wq, const float *__restrict__ b, int Cout,
-                                                                float *__restrict__ y)
+                                                                float *__restrict__ y, int halo)
 {
+    auto opix = [&](int64_t q) -> int64_t {                              // output pixel index of input pixel q
+        if (!halo) return q;
+        const int64_t qn = q / ((int64_t)H * W);
+        const int qr = (int)(q - qn * H * W), qy = qr / W, qx = qr - qy * W;
+        return (qn * (H + 2) + qy + 1) * (W + 2) + qx + 1;
+    };
     __shared__ __attribute__((aligned(16))) float tile_s[T16 ? 4 * 64 * 16 : 4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -184,6 +191,9 @@ __global__ __launch_bounds__(256) void conv3x3_c4_direct_kernel(const float4 *__
     if constexpr (T16) {
         float *tile = tile_s + wv * 64 * 16;
         const int64_t pw = (int64_t)blockIdx.x * 256 + wv * 64;         // the wave's first pixel
+        int64_t op[4];                                                   // where this lane's four transposed stores of a round go
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int64_t q = pw + (lane >> 2) + 16 * j; op[j] = opix(q < pixels ? q : pixels - 1); }
         for (int co = 0; co < Cout; co += 16) {
             float4 o[4];
 #pragma unroll
@@ -196,14 +206,14 @@ __global__ __launch_bounds__(256) void conv3x3_c4_direct_kernel(const float4 *__
             for (int j = 0; j < 4; ++j) {
                 const int pl = (lane >> 2) + 16 * j;
                 const float4 v = *reinterpret_cast<const float4 *>(tile + pl * 16 + 4 * (lane & 3));
-                if (pw + pl < pixels) *reinterpret_cast<float4 *>(y + (pw + pl) * Cout + co + 4 * (lane & 3)) = v;
+                if (pw + pl < pixels) *reinterpret_cast<float4 *>(y + op[j] * Cout + co + 4 * (lane & 3)) = v;
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
         }
     } else {
         if (p >= pixels) return;
-        float4 *yo = reinterpret_cast<float4 *>(y + p * Cout);
+        float4 *yo = reinterpret_cast<float4 *>(y + opix(p) * Cout);
         for (int co = 0; co < Cout; co += 4) yo[co >> 2] = quad(co);
     }
 }
@@ -229,9 +239,27 @@ __global__ __launch_bounds__(256) void maxpool2_nhwc_kernel(const float *__restr
     reinterpret_cast<float4 *>(y)[i] = o;
 }
 
-// NHWC [B,H,W,C] -> [B, C*49] in torch's flatten order (channel-major), windows as AdaptiveAvgPool2d((7,7))
+// zero border of a halo-padded NHWC tensor [B][H + 2][W + 2][C] (C % 4 == 0): the 2 (W + 2) + 2 H border pixels of every image
+__global__ __launch_bounds__(256) void halo_border_zero_kernel(float *__restrict__ x, int64_t B, int H, int W, int C)
+{
+    const int C4 = C / 4, nb = 2 * (W + 2) + 2 * H;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * nb * C4) return;
+    const int c4 = (int)(i % C4);
+    const int64_t r = i / C4;
+    const int bi = (int)(r % nb);
+    const int64_t n = r / nb;
+    int py, px;
+    if (bi < W + 2) { py = 0; px = bi; }
+    else if (bi < 2 * (W + 2)) { py = H + 1; px = bi - (W + 2); }
+    else { const int k = bi - 2 * (W + 2); py = 1 + (k >> 1); px = (k & 1) ? W + 1 : 0; }
+    reinterpret_cast<float4 *>(x)[((n * (H + 2) + py) * (W + 2) + px) * C4 + c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// NHWC [B,H,W,C] -> [B, C*49] in torch's flatten order (channel-major), windows as AdaptiveAvgPool2d((7,7)); halo != 0: the input
+// is the interior of a [B][H + 2][W + 2][C] tensor
 __global__ __launch_bounds__(256) void adaptive_avgpool7_nhwc_kernel(const float *__restrict__ x, int64_t B, int H, int W,
-                                                                     int C, float *__restrict__ y)
+                                                                     int C, float *__restrict__ y, int halo)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * C * 49) return;
@@ -240,7 +268,8 @@ __global__ __launch_bounds__(256) void adaptive_avgpool7_nhwc_kernel(const float
     const int y0 = (oy * H) / 7, y1 = ((oy + 1) * H + 6) / 7, x0 = (ox * W) / 7, x1 = ((ox + 1) * W + 6) / 7;
     float acc = 0.0f;
     for (int iy = y0; iy < y1; ++iy)
-        for (int ix = x0; ix < x1; ++ix) acc = acc + x[((n * H + iy) * W + ix) * (int64_t)C + c];
+        for (int ix = x0; ix < x1; ++ix)
+            acc = acc + (halo ? x[((n * (H + 2) + iy + 1) * (W + 2) + ix + 1) * (int64_t)C + c] : x[((n * H + iy) * W + ix) * (int64_t)C + c]);
     y[i] = acc / (float)((y1 - y0) * (x1 - x0));
 }
 
@@ -287,6 +316,7 @@ static VggPlan plan_vgg(int chunk, int H, int W, const int *cfg, int ncfg)
     size_t cur = (size_t)chunk * 4 * H * W;
     p.act_elems = cur;
     int cin = 4;
+    auto padded = [&](int c, int h, int w) { return (size_t)chunk * c * (h + 2) * (w + 2); };    // (a halo-padded stage needs this much)
     for (int i = 0; i < ncfg; ++i) {
         if (cfg[i] > 0) {
             if (cfg[i] % 4) p.ok = false;                 // NHWC float4 path
@@ -296,7 +326,7 @@ static VggPlan plan_vgg(int chunk, int H, int W, const int *cfg, int ncfg)
             if (p.h_last < 2 || p.w_last < 2) p.ok = false;
             p.h_last /= 2; p.w_last /= 2;
         }
-        cur = (size_t)chunk * p.c_last * p.h_last * p.w_last;
+        cur = padded(p.c_last, p.h_last, p.w_last);
         if (cur > p.act_elems) p.act_elems = cur;
     }
     if (p.h_last < 1 || p.w_last < 1) p.ok = false;
@@ -383,6 +413,22 @@ int vfr_vgg_fc7_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *
     // the stack's first convolution (3 channels, K = 36) takes the direct kernel unless a pool is fused behind it
     const bool direct1 = vfr::opt_vgg_direct1() && cfg_host[0] > 0 && (cfg_host[0] % 4) == 0 &&
                          !(vfr::opt_vgg_fuse_pool() && ncfg > 1 && cfg_host[1] <= 0 && ((H | W) & 1) == 0);
+    // halo-padded stack (gemm.hip CHALO: no tap masks, no selects in the convolution loader): every activation behind the first
+    // convolution lives in the interior of a [B][h + 2][w + 2][C] tensor with a zero border.  Needs the direct first convolution,
+    // every later convolution with C_in % 32 == 0, and every pool fusable into the convolution in front of it.
+    bool halo = vfr::opt_vgg_halo() && direct1 && vfr::opt_vgg_fuse_pool();
+    {
+        int hh = H, ww = W, cc = cfg_host[0];
+        bool prev_conv = true;
+        for (int i = 1; i < ncfg && halo; ++i) {
+            if (cfg_host[i] > 0) { if (cc % 32) halo = false; cc = cfg_host[i]; prev_conv = true; }
+            else { if (!prev_conv || i == 1 || ((hh | ww) & 1)) halo = false; hh /= 2; ww /= 2; prev_conv = false; }
+        }
+    }
+    auto zero_border = [&](float *buf, int bt, int h, int w, int c) {
+        const int64_t n = (int64_t)bt * (2 * (w + 2) + 2 * h) * (c / 4);
+        hipLaunchKernelGGL(vfr::halo_border_zero_kernel, dim3((unsigned)vfr::cdiv(n, 256)), dim3(256), 0, st, buf, (int64_t)bt, h, w, c);
+    };
     // repack every conv weight once per call: [Cout,Cin,3,3] -> [Cout, 9*Cinp] tap-major (the chain order)
     {
         vfr::ProfScope prof(vfr::SITE_REPACK, st);
@@ -428,16 +474,21 @@ int vfr_vgg_fc7_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *
                 // the full-resolution activation is never written, the pool kernel never runs
                 const bool pool = vfr::opt_vgg_fuse_pool() && i + 1 < ncfg && cfg_host[i + 1] <= 0 && ((h | w) & 1) == 0;
                 if (pool) g.epi |= vfr::EPI_POOL2;
+                if (halo) {                    // the destination's border for the geometry this layer writes
+                    vfr::ProfScope prof(vfr::SITE_POOL2D, st);
+                    zero_border(nxt, bt, pool ? h / 2 : h, pool ? w / 2 : w, cout);
+                    g.conv_halo = conv > 0 ? 1 : 0;
+                }
                 if (conv == 0 && direct1) {
                     vfr::ProfScope prof(vfr::SITE_CONV, st);
                     if (cout % 16 == 0)
                         hipLaunchKernelGGL(vfr::conv3x3_c4_direct_kernel<true>, dim3((unsigned)vfr::cdiv(g.M, 256)), dim3(256), 0, st,
                                            reinterpret_cast<const float4 *>(cur), g.M, h, w, reinterpret_cast<const float4 *>(wr),
-                                           conv_b_host[conv], cout, nxt);
+                                           conv_b_host[conv], cout, nxt, halo ? 1 : 0);
                     else
                         hipLaunchKernelGGL(vfr::conv3x3_c4_direct_kernel<false>, dim3((unsigned)vfr::cdiv(g.M, 256)), dim3(256), 0, st,
                                            reinterpret_cast<const float4 *>(cur), g.M, h, w, reinterpret_cast<const float4 *>(wr),
-                                           conv_b_host[conv], cout, nxt);
+                                           conv_b_host[conv], cout, nxt, halo ? 1 : 0);
                 } else
                 if (int rc = vfr::gemm_nt(g, st)) return rc;
                 wr += vfr::align_up((size_t)cout * 9 * c, 64);
@@ -457,7 +508,7 @@ int vfr_vgg_fc7_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *
         {
             vfr::ProfScope prof(vfr::SITE_POOL2D, st);
             hipLaunchKernelGGL(vfr::adaptive_avgpool7_nhwc_kernel, dim3((unsigned)vfr::cdiv((int64_t)bt * c * 49, 256)),
-                               dim3(256), 0, st, cur, (int64_t)bt, h, w, c, pooled + (size_t)t0 * K6);
+                               dim3(256), 0, st, cur, (int64_t)bt, h, w, c, pooled + (size_t)t0 * K6, halo ? 1 : 0);
         }
         VFR_CHECK_LAUNCH("adaptive_avgpool7_nhwc_kernel");
     }
