@@ -302,7 +302,9 @@ int vfr_math_f32(int op, const float *x, const float *y, float *out, int64_t n, 
  * "lstm_persist_min" (default 2) at the model's shape: weights resident in registers as MFMA fragments -- with h handed between
  * workgroups as tagged granules | one launch per step), "score_smallq_select" 1|0 (few-queries top-k by video selection | key
  * array + selection tree), "vgg_fuse_pool" 1|0 (a 2x2 max-pool behind a VGG convolution runs in that convolution's epilogue |
- * its own kernel), "vgg_direct1" 1|0 (first VGG convolution as the direct kernel | the implicit-GEMM MFMA kernel)
+ * its own kernel), "vgg_direct1" 1|0 (first VGG convolution as the direct kernel | the implicit-GEMM MFMA kernel), "vgg_halo" 1|0 (the VGG stack on
+ * halo-padded activations where its shape allows: convolution loader without tap masks | unpadded), "lstm_fast" 1|0 (the
+ * select-free instantiation of the table-start LSTM step where the launch qualifies | always the general form)
  * -- same bits either way.                                                                       */
 int vfr_set_option(const char *name, int value);
 int vfr_get_option(const char *name);
