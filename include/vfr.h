@@ -85,14 +85,28 @@ int vfr_linear_f32(const float *A, int64_t M, int K, const float *W, const float
  * 3 <= B <= 32 at E = 100, H = 1000 (weights resident in registers as MFMA fragments): the
  * whole sequence and the Linear run as ONE launch of 2 * ceil(H / 8) workgroups that wait on each other's h every step, so
  * ALL of them must be resident: do not run two such calls concurrently on one device (two streams / processes can starve
- * each other of CUs).  The waits are bounded: a call that gives up fills `out` with NaN (and raises an error word inside
- * its workspace).  vfr_set_option("lstm_persist", 0) selects one launch per step instead.                         */
+ * each other of CUs -- the host checks the grid against the device's CU count, it cannot see what else is running).  The
+ * waits are bounded, and a give-up is REPAIRED inside the same call: behind every such launch a rescue kernel is enqueued
+ * that returns at once in the normal case and otherwise re-encodes the batch without any cross-workgroup dependency (one
+ * workgroup per query; milliseconds) -- `out` never holds NaN from a give-up and the return code stays VFR_OK because the
+ * result is right.  The event is reported through the fault word: vfr_set_fault_word / vfr_poll_faults below.
+ * vfr_set_option("lstm_persist", 0) selects one launch per step instead.                                            */
 size_t vfr_bilstm_workspace_bytes(int64_t B, int T, int E, int H, int vocab);
 int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *emb, int vocab, const float *len_tab,
                          const float *Wih_f, const float *Whh_f, const float *bih_f, const float *bhh_f,
                          const float *Wih_b, const float *Whh_b, const float *bih_b, const float *bhh_b, int E,
                          int H, const float *Wfc, const float *bfc, int D, float *out, void *workspace,
                          size_t workspace_bytes, vfr_stream_t stream);
+
+/* Fault word: kernels cannot return codes, and no entry point synchronises.  A caller that wants to HEAR about device-side
+ * recoveries registers one device-accessible HOST word (page-locked: hipHostMalloc / torch pin_memory; process-wide, any
+ * device; NULL unregisters; it must outlive every call made while registered).  Kernels raise bits in it with system-scope
+ * atomics; vfr_poll_faults() (host only, no synchronisation: poll after the caller's own sync point) returns and clears the
+ * bits raised since the last poll and leaves the explanation in vfr_last_error().
+ *   VFR_FAULT_SEQ_RESCUED  a single-launch sequence encoder gave up and the batch was re-encoded by the rescue kernel     */
+#define VFR_FAULT_SEQ_RESCUED 1
+int vfr_set_fault_word(uint32_t *word_host);
+int vfr_poll_faults(void);
 
 /* ---- a10  scoring core: model/evaluate.py:49-58 (same code evaluate_single.py:48-53,
  * main.py:148-157).  dist[c] = ||(V[c] - q) + eps||_2 (F.pairwise_distance), score of moment

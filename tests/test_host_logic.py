@@ -439,6 +439,7 @@ def test_extract_dataset_resume_and_missed_bookkeeping(tmp_path, monkeypatch):
     calls.clear()
     written, _ = features.extract_dataset(info, decoder, ft, None, model_type="resnet152", missed_path=missed_file)
     assert written == ["v0", "v1", "v4"] and (ft / "resnet152_ft_v1.npy").exists() and len(calls) == 3
+    assert np.load(ft / "resnet152_ft_v0.npy").shape == (125, 4, 1, 1)           # the reference's [T, C, 1, 1] (get_rgb_features.py:129-131,151)
     with pytest.raises(ValueError):
         features.extract_dataset(info, decoder, ft, None, model_type="resnet50", missed_path=missed_file)
 

@@ -28,6 +28,8 @@ SIGNATURES = {
     "vfr_last_error": (ctypes.c_char_p, []),
     "vfr_set_option": (_i32, [ctypes.c_char_p, _i32]),
     "vfr_get_option": (_i32, [ctypes.c_char_p]),
+    "vfr_set_fault_word": (_i32, [_vp]),
+    "vfr_poll_faults": (_i32, []),
     "vfr_profile_sites": (_i32, []),
     "vfr_profile_site_name": (ctypes.c_char_p, [_i32]),
     "vfr_profile_read": (_i32, [_i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), _i32]),
@@ -131,6 +133,38 @@ def get_option(name: str) -> int:
     return int(lib().vfr_get_option(name.encode()))
 
 
+FAULT_SEQ_RESCUED = 1                      # include/vfr.h VFR_FAULT_SEQ_RESCUED
+_FAULT_WORD = None                         # page-locked int32 word the kernels raise fault bits in (registered once per process)
+FAULT_LOG = []                             # (bits, message) of every fault poll_faults() has reported
+
+
+def _register_fault_word() -> None:
+    """Give the library its fault word (include/vfr.h vfr_set_fault_word): device-side recoveries -- a single-launch sequence
+    encoder that gave up and was re-encoded by the rescue kernel -- are reported through it, lazily, by ``poll_faults``."""
+    global _FAULT_WORD
+    if _FAULT_WORD is None:
+        word = torch.zeros(1, dtype=torch.int32).pin_memory()
+        _check(lib().vfr_set_fault_word(word.data_ptr()), "vfr_set_fault_word")
+        _FAULT_WORD = word
+
+
+def poll_faults() -> int:
+    """Fault bits raised on the device since the last poll (0: none).  Host-only, never synchronises: call it after a point
+    where the work of interest has completed (``.cpu()`` / ``.item()`` / ``torch.cuda.synchronize()``); the wrappers of the
+    entry points that can raise a fault also poll on entry, so a fault is reported at the latest by the next such call.
+    Every reported fault is a ``RuntimeWarning`` carrying ``vfr_last_error()`` and an entry of ``FAULT_LOG`` -- the results
+    of the affected call were REPAIRED on the device (include/vfr.h), nothing needs re-running."""
+    if _FAULT_WORD is None:
+        return 0
+    bits = int(lib().vfr_poll_faults())
+    if bits:
+        import warnings
+        msg = lib().vfr_last_error().decode()
+        FAULT_LOG.append((bits, msg))
+        warnings.warn(f"vfr: device-side recovery (fault bits {bits:#x}): {msg}", RuntimeWarning, stacklevel=2)
+    return bits
+
+
 def profile_read(reset: bool = True) -> dict:
     """{site name: (total device ms, launches)} since the last reset.  Synchronise the device first."""
     l = lib()
@@ -224,6 +258,8 @@ def bilstm_final(tokens, emb, lstm: dict, Wfc, bfc, len_tab=None) -> torch.Tenso
     lt = _dev(len_tab, torch.float32, "len_tab") if len_tab is not None else None
     B, T = tokens.shape
     E, H, D = emb.shape[1], ws_[1].shape[1], Wfc.shape[0]
+    _register_fault_word()
+    poll_faults()                              # (a give-up of an EARLIER call's sequence kernel: repaired there, reported here)
     out = torch.empty((B, D), dtype=torch.float32, device=tokens.device)
     nbytes = lib().vfr_bilstm_workspace_bytes(B, T, E, H, emb.shape[0])
     ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=tokens.device)

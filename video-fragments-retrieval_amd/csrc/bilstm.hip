@@ -10,6 +10,7 @@
 //   out  [B, D]     = [h_fwd | h_bwd] x Wfc^T + bfc
 //
 // 352.4 MFLOP per query; the recurrent GEMM [B,H]x[H,4H] is the MFMA-bound part.
+#include <atomic>
 #include <type_traits>
 
 #include "vfr_common.h"
@@ -402,7 +403,8 @@ __global__ __launch_bounds__(64 * (S4_NL + 1), 1) void lstm_step_small4_kernel(S
 // step ahead of the slowest one (it needs that one's h to go further).  Same chains in the same order as the step kernels:
 // identical bits (tests: lstm_persist 0 vs 1, and the oracle).
 // Every workgroup must be resident (the host checks grid <= CU count; 150 KB of LDS = one workgroup per CU); the sweeps are
-// bounded: a workgroup that gives up raises a.err, poisons its outputs with NaN and leaves, and so do all the others.
+// bounded: a workgroup that gives up raises a.err, poisons its outputs with NaN and leaves, and so do all the others -- and
+// lstm_seq_rescue_kernel, enqueued behind every launch, then re-encodes the batch (below): the CALL never returns NaN.
 typedef __attribute__((address_space(1))) unsigned long long seq_gu64;
 struct SeqLstm {
     const float *X;                       // [B*T, E] embedded tokens
@@ -843,17 +845,110 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_mfma_kernel(SeqLstm a)
     if (dead && tid == 0) atomicOr(a.err, 1u);
 }
 
-// the sequence kernels declare up to 160 KB of dynamic LDS: asked for once per kernel; a device / runtime that refuses keeps
-// the per-step paths
+// ---- rescue of a sequence kernel that gave up ----------------------------------------------------------------------------
+// Enqueued behind EVERY launch of the two single-launch sequence kernels; returns at once when the error word is clear (the
+// normal case: one empty launch).  When a sweep gave up (some workgroup of the grid was not resident: another stream or
+// process held its CU) the outputs are NaN by construction, and this kernel re-encodes the batch with NO cross-workgroup
+// dependency: one workgroup per query runs both directions and lang_fc by itself -- thread = hidden unit (H <= 1024), the
+// four gate chains of its unit over [x_t | h] (k ascending from zero, the h part skipped at step 0, bias pair after the
+// chain: the sequence kernels' order, hence the oracle's bits), h handed from step to step through LDS.  Slow (every
+// workgroup streams all of [W_ih | W_hh] per step: milliseconds) and rare; it makes the call's result right instead of NaN,
+// raises bit 1 of the error word and bit 0 of the host fault word (vfr_set_fault_word) so that the caller hears about it.
+__global__ __launch_bounds__(1024) void lstm_seq_rescue_kernel(SeqLstm a, unsigned *fault_word_host)
+{
+    if (*a.err == 0u) return;
+    extern __shared__ __attribute__((aligned(16))) float seq_lds[];
+    const int E = a.E, H = a.H, T = a.T, K2 = 2 * H;
+    float *xh = seq_lds;                  // [E + H]: this step's embedded token | the previous step's h
+    float *hfin = xh + E + H;             // [2H]: final [h_fwd | h_bwd]
+    const int b = blockIdx.x, u = threadIdx.x;
+    const bool on = u < H;
+    const int uc = on ? u : H - 1;
+    for (int d = 0; d < 2; ++d) {
+        float bsum[4], cst = 0.0f, hn = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bsum[g] = a.bih[d][g * H + uc] + a.bhh[d][g * H + uc];
+        for (int step = 0; step < T; ++step) {
+            const int t = d ? T - 1 - step : step;
+            for (int k = u; k < E; k += 1024) xh[k] = a.X[((size_t)b * T + t) * E + k];
+            __syncthreads();                                      // x_t and the previous step's h are in place
+            if (on) {
+                float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (int k4 = 0; k4 < E / 4; ++k4) {
+                    const float4 x = *reinterpret_cast<const float4 *>(xh + 4 * k4);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 w = *reinterpret_cast<const float4 *>(a.Wih[d] + ((size_t)g * H + u) * E + 4 * k4);
+                        acc[g] = __builtin_fmaf(x.x, w.x, acc[g]); acc[g] = __builtin_fmaf(x.y, w.y, acc[g]);
+                        acc[g] = __builtin_fmaf(x.z, w.z, acc[g]); acc[g] = __builtin_fmaf(x.w, w.w, acc[g]);
+                    }
+                }
+                if (step > 0)
+                    for (int k4 = 0; k4 < H / 4; ++k4) {
+                        const float4 x = *reinterpret_cast<const float4 *>(xh + E + 4 * k4);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 w = *reinterpret_cast<const float4 *>(a.Whh[d] + ((size_t)g * H + u) * H + 4 * k4);
+                            acc[g] = __builtin_fmaf(x.x, w.x, acc[g]); acc[g] = __builtin_fmaf(x.y, w.y, acc[g]);
+                            acc[g] = __builtin_fmaf(x.z, w.z, acc[g]); acc[g] = __builtin_fmaf(x.w, w.w, acc[g]);
+                        }
+                    }
+                const float ig = c_sigmoidf(acc[0] + bsum[0]);
+                const float fg = c_sigmoidf(acc[1] + bsum[1]);
+                const float gg = c_tanhf(acc[2] + bsum[2]);
+                const float og = c_sigmoidf(acc[3] + bsum[3]);
+                cst = __builtin_fmaf(fg, cst, ig * gg);
+                hn = og * c_tanhf(cst);
+            }
+            __syncthreads();                                      // every chain has read the old h
+            if (on) xh[E + u] = hn;
+        }
+        if (on) {
+            hfin[d * H + u] = hn;
+            a.hout[(size_t)b * K2 + (size_t)d * H + u] = hn;
+        }
+        __syncthreads();
+    }
+    if (a.Wfc)
+        for (int o = u; o < a.D; o += 1024) {
+            const float *wr = a.Wfc + (size_t)o * K2;
+            float s = 0.0f;
+            for (int k4 = 0; k4 < K2 / 4; ++k4) {
+                const float4 w = *reinterpret_cast<const float4 *>(wr + 4 * k4);
+                const float4 x = *reinterpret_cast<const float4 *>(hfin + 4 * k4);
+                s = __builtin_fmaf(x.x, w.x, s); s = __builtin_fmaf(x.y, w.y, s);
+                s = __builtin_fmaf(x.z, w.z, s); s = __builtin_fmaf(x.w, w.w, s);
+            }
+            a.out[(size_t)b * a.D + o] = s + a.bfc[o];
+        }
+    if (b == 0 && u == 0) {
+        // (the word only ever GAINS bits: a workgroup that starts after this one still sees it raised)
+        atomicOr(a.err, 2u);
+        if (fault_word_host) __hip_atomic_fetch_or(fault_word_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+static int launch_seq_rescue(const SeqLstm &a, hipStream_t st)
+{
+    const size_t lds = ((size_t)a.E + 3 * (size_t)a.H) * sizeof(float);
+    hipLaunchKernelGGL(lstm_seq_rescue_kernel, dim3((unsigned)a.B), dim3(1024), lds, st, a, fault_word());
+    return hipGetLastError() == hipSuccess ? VFR_OK : fail(VFR_EHIP, "lstm_seq_rescue_kernel: launch failed");
+}
+
+// the sequence kernels declare up to 160 KB of dynamic LDS: asked for once per kernel AND DEVICE; a device / runtime that
+// refuses keeps the per-step paths
 template <typename K>
 static bool seq_lds_admitted(K kernel)
 {
-    static int state = -1;
-    if (state < 0) {
-        state = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : 0;
-        if (!state) (void)hipGetLastError();
+    static std::atomic<signed char> state[VFR_MAX_DEVICES];           // 0: not asked yet, 1: admitted, -1: refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VFR_MAX_DEVICES) { (void)hipGetLastError(); return false; }
+    signed char v = state[dev].load();
+    if (v == 0) {
+        v = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : -1;
+        if (v < 0) (void)hipGetLastError();
+        state[dev].store(v);
     }
-    return state == 1;
+    return v == 1;
 }
 
 struct LstmWs {
@@ -955,6 +1050,7 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
         else              hipLaunchKernelGGL((vfr::lstm_seq_mfma_kernel<2, 2, 25, 275>), grid, dim3(256), lds, st, a);
         }
         VFR_CHECK_LAUNCH("lstm_seq_mfma_kernel");
+        if (int rc = vfr::launch_seq_rescue(a, st)) return rc;         // no-op unless a sweep gave up: then the batch is re-encoded (never NaN)
         if (fc_in) return VFR_OK;
         vfr::GemmArgs g{};
         g.A = w.hcat; g.lda = 2 * H; g.W = Wfc; g.ldw = 2 * H; g.out = out; g.ldo = D; g.M = B; g.N = D; g.K = 2 * H;
@@ -990,6 +1086,7 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
             else        hipLaunchKernelGGL(vfr::lstm_seq_small_kernel<2>, dim3((unsigned)seq_grid), dim3(256), seq_lds, st, a);
             }
             VFR_CHECK_LAUNCH("lstm_seq_small_kernel");
+            if (int rc = vfr::launch_seq_rescue(a, st)) return rc;
             if (fc_in) return VFR_OK;
             vfr::GemmArgs g{};
             g.A = w.hcat; g.lda = 2 * H; g.W = Wfc; g.ldw = 2 * H; g.out = out; g.ldo = D; g.M = B; g.N = D; g.K = 2 * H;

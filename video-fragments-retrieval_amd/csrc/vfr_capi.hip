@@ -107,15 +107,17 @@ int opt_vgg_halo() { return g_opt_vgg_halo; }
 int opt_score_smallq_select() { return g_opt_smallq_select; }
 int device_cu_count()
 {
-    static std::atomic<int> cus{-1};
-    int v = cus.load();
-    if (v < 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        cus.store(v = n);
-    }
-    return v;
+    static std::atomic<int> cus[VFR_MAX_DEVICES];                     // 0: not asked yet (a device has at least one CU)
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const bool cached = dev >= 0 && dev < VFR_MAX_DEVICES;
+    if (cached && (n = cus[dev].load()) > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    if (cached && n > 0) cus[dev].store(n);
+    return n;
 }
+static std::atomic<unsigned *> g_fault_word{nullptr};
+unsigned *fault_word() { return g_fault_word.load(); }
 int opt_lstm_small() { return g_opt_lstm_small; }
 int opt_gemm_pp() { return g_opt_gemm_pp; }
 int opt_mfma_min() { return g_opt_mfma_min; }
@@ -155,6 +157,23 @@ int vfr_get_option(const char *name)
     for (const auto &o : vfr::g_opts)
         if (name && !strcmp(name, o.name)) return o.v->load();
     return vfr::fail(VFR_EINVAL, "vfr_get_option: unknown option '%s'", name ? name : "(null)");
+}
+
+int vfr_set_fault_word(uint32_t *word_host)
+{
+    vfr::g_fault_word.store(reinterpret_cast<unsigned *>(word_host));
+    return VFR_OK;
+}
+int vfr_poll_faults(void)
+{
+    unsigned *w = vfr::g_fault_word.load();
+    if (!w) return 0;
+    const unsigned bits = __atomic_exchange_n(w, 0u, __ATOMIC_ACQ_REL);
+    if (bits & VFR_FAULT_SEQ_RESCUED)
+        (void)vfr::fail(0, "vfr_bilstm_final_f32: a single-launch sequence encoder gave up waiting for a workgroup that was not resident "
+                           "(another stream / process on the device); the batch was re-encoded by lstm_seq_rescue_kernel -- results "
+                           "are correct, the call was slow.  Do not run such calls concurrently, or set lstm_persist 0");
+    return (int)bits;
 }
 
 int vfr_profile_sites(void) { return vfr::SITE_COUNT; }

@@ -36,7 +36,9 @@ int opt_lstm_persist_fault();
 int opt_vgg_fuse_pool();
 int opt_vgg_direct1();
 int opt_vgg_halo();
-int device_cu_count();
+int device_cu_count();                  // of the CURRENT device (cached per device)
+constexpr int VFR_MAX_DEVICES = 64;     // per-device caches (CU count, kernel attributes)
+unsigned *fault_word();                 // vfr_set_fault_word: device-accessible host word kernels raise fault bits in (nullable)
 int opt_lstm_small();
 int opt_gemm_pp();
 int opt_mfma_min();

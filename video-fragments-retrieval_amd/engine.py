@@ -53,6 +53,10 @@ class HipOps:
     def slice_bank(self, bank, counts, v0, v1):
         return self.v.slice_bank(bank, counts, v0, v1)
 
+    def poll_faults(self):
+        """Device-side recoveries since the last poll (``_vfr.poll_faults``: a RuntimeWarning each; results were repaired)."""
+        return self.v.poll_faults()
+
     def topk_merge(self, part_dist, part_idx):
         return self.v.topk_merge(part_dist, part_idx)
 
@@ -463,6 +467,7 @@ def corpus_ranks(shard: CorpusShard, Q, own_global, labels, ops=None, k=0, world
     def check():
         if state["async"]:
             state["landed"].synchronize()
+            getattr(ops, "poll_faults", int)()       # the query encoder finished before the keys: a give-up of its sequence kernel is known by now
         if bool(state["flag"] if state["async"] else state["missing"]):
             raise IndexError("index 0 is out of bounds for axis 0 with size 0 (no ground-truth-positive moment)")
     if fused:

@@ -85,14 +85,18 @@ def extract_video(frames_u8, fps: float, num_segments: int, weights, cfg=None, m
 
 
 def extract_dataset(dataset_info, decoder, features_dir, weights, model_type: str = "vgg19", cfg=None,
-                    missed_path="missed_videos_features.json", pipeline: bool = True):
+                    missed_path="missed_videos_features.json", pipeline: bool = True, progress=None, stats=None):
     """The extraction loop with the reference's resume / skip-and-record behaviour.  Returns (written, missed) video lists.
 
     ``pipeline=True`` (ROCm device only): the loop of ``get_rgb_features.py:134-153`` as a three-stage pipeline -- a reader thread
     decodes video i + 1 into page-locked memory while the device runs the stack on video i (frames H2D, index-select,
     normalise, the whole network: all queued asynchronously on the compute stream), and a writer thread waits for video
     i - 1's D2H copy (into a page-locked slot, behind an event) and ``np.save``s it.  The device never waits for the decoder, the
-    copy back or the file system; files and lists are those of the serial loop."""
+    copy back or the file system; files and lists are those of the serial loop (``written`` lists a video once its file is
+    saved).  ``progress(video)``: called by the device loop after a video is queued (measurement hook); ``stats`` (a dict, if
+    given) receives ``max_write_queue`` = the deepest the writer's queue got.
+    Files have the reference's shapes: ``[T, 4096]`` for vgg19, ``[T, 2048, 1, 1]`` for resnet152 (``children()[:-1]`` ends in the
+    average pool, ``get_rgb_features.py:129-131``; ``model/data.py:166`` reshapes either)."""
     if model_type not in ("vgg19", "resnet152"):
         raise ValueError(f"unknown extractor {model_type!r} (get_rgb_features.py:122-131 has vgg19 and resnet152)")
     ft = Path(features_dir)
@@ -105,6 +109,8 @@ def extract_dataset(dataset_info, decoder, features_dir, weights, model_type: st
     todo = [item for item in dataset_info if item["video"] not in skip]                       # (:115-116)
     dev = _weights_device(weights, model_type)
     written = []
+    stats = stats if stats is not None else {}
+    stats["max_write_queue"] = 0
     if not (pipeline and dev is not None and dev.type == "cuda"):
         for item in todo:
             video, nseg = item["video"], item["num_segments"]
@@ -113,7 +119,7 @@ def extract_dataset(dataset_info, decoder, features_dir, weights, model_type: st
                 missed.append(video)
                 continue
             feats = extract_video(frames, fps, nseg, weights, cfg, model_type)
-            np.save(ft / f"{prefix}{video}", feats.cpu().numpy())                            # (:150-151)
+            np.save(ft / f"{prefix}{video}", _file_shape(feats.cpu().numpy(), model_type))  # (:150-151)
             written.append(video)
         missed_path.write_text(json.dumps(missed))                                           # (:155-156)
         return written, missed
@@ -150,7 +156,9 @@ def extract_dataset(dataset_info, decoder, features_dir, weights, model_type: st
                     return
                 video, event, host = job
                 event.synchronize()
-                np.save(ft / f"{prefix}{video}", host.numpy())                               # (:150-151)
+                np.save(ft / f"{prefix}{video}", _file_shape(host.numpy(), model_type))     # (:150-151)
+                written.append(video)                                                        # only once the file exists
+                stats["max_write_queue"] = max(stats["max_write_queue"], to_write.qsize())
         except BaseException as e:              # noqa: BLE001
             errors.append(e)
             while to_write.get() is not None:   # keep draining so the main thread never blocks on a full queue
@@ -160,21 +168,25 @@ def extract_dataset(dataset_info, decoder, features_dir, weights, model_type: st
     for t in threads:
         t.start()
     try:
-        while True:
-            job = decoded.get()
-            if job is None:
-                break
-            video, nseg, frames, fps = job
-            if frames is None:                                                                # (:75-78,152-153)
-                missed.append(video)
-                continue
-            feats = extract_video(frames.to(dev, non_blocking=True), fps, nseg, weights, cfg, model_type)
-            host = torch.empty(feats.shape, dtype=feats.dtype, pin_memory=True)
-            host.copy_(feats, non_blocking=True)
-            event = torch.cuda.Event()
-            event.record()
-            to_write.put((video, event, host))
-            written.append(video)
+        # everything below is queued on the current stream OF THE WEIGHTS' DEVICE: the event that releases a slot to the writer
+        # must be recorded on the stream that carries the D2H copy, whatever the caller's current device is
+        with torch.cuda.device(dev):
+            while True:
+                job = decoded.get()
+                if job is None:
+                    break
+                video, nseg, frames, fps = job
+                if frames is None:                                                            # (:75-78,152-153)
+                    missed.append(video)
+                    continue
+                feats = extract_video(frames.to(dev, non_blocking=True), fps, nseg, weights, cfg, model_type)
+                host = torch.empty(feats.shape, dtype=feats.dtype, pin_memory=True)
+                host.copy_(feats, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record(torch.cuda.current_stream(dev))
+                to_write.put((video, event, host))
+                if progress is not None:
+                    progress(video)
     finally:
         stop.set()
         while threads[0].is_alive():            # an exception above: let the reader finish its put, then stop
@@ -189,6 +201,11 @@ def extract_dataset(dataset_info, decoder, features_dir, weights, model_type: st
         raise errors[0]
     missed_path.write_text(json.dumps(missed))                                               # (:155-156)
     return written, missed
+
+
+def _file_shape(feats: np.ndarray, model_type: str) -> np.ndarray:
+    """The array as the reference writes it (get_rgb_features.py:147-151): resnet152 keeps the pooled map's two unit axes."""
+    return feats.reshape(feats.shape[0], -1, 1, 1) if model_type == "resnet152" else feats
 
 
 def _weights_device(weights, model_type):
