@@ -1433,7 +1433,7 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
 namespace vfr {
 struct MfmaWs {
     float *rv; BankSig *sig; unsigned long long *hash_now; int *stale; int *fallback; unsigned long long *pairs_total; unsigned long long *cnt_ws; size_t zero_bytes; char *zero_base;
-    float *va; float4 *qmeta; unsigned *tab; unsigned *wmax; unsigned short *vb; ulonglong2 *amb; int tasks, groups;
+    float *va; float4 *qmeta; unsigned *tab; unsigned *wmax, *qbound; unsigned short *vb; ulonglong2 *amb; int tasks, groups;
     float *mu, *vc, *qc; double *mean_partial; int mean_blocks, mean_rows;
     void *topk; size_t topk_bytes; size_t total;
 };
@@ -1465,6 +1465,7 @@ static MfmaWs carve_mfma(void *base, int64_t Nq, int Nv, int total_clips, int k)
     w.pairs_total = reinterpret_cast<unsigned long long *>(take(8));
     w.cnt_ws = reinterpret_cast<unsigned long long *>(take((size_t)MAX_RANK * Nq * 8));
     w.wmax = reinterpret_cast<unsigned *>(take((size_t)Nq * 4));
+    w.qbound = reinterpret_cast<unsigned *>(take((size_t)Nq * 8));
     w.zero_bytes = off - z0;
     w.qc = reinterpret_cast<float *>(take((size_t)Nq * FAST_D * 4));
     w.qmeta = reinterpret_cast<float4 *>(take((size_t)Nq * 16));
@@ -1951,6 +1952,7 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
     vfr::MfmaArgs m{};
     m.va = mw.va; m.qmeta = mw.qmeta; m.tab = mw.tab; m.cnt_ws = mw.cnt_ws; m.amb = mw.amb; m.pairs_total = mw.pairs_total; m.wmax = mw.wmax;
     m.fallback = mw.fallback; m.vb = bf16 ? mw.vb : nullptr; m.rv = mw.rv; m.vc = mw.vc; m.qc = mw.qc;
+    m.qbound = mw.qbound; m.defer_max = vfr::opt_score_defer();
     {
         vfr::ProfScope prof(vfr::SITE_SCORE_PREP, st);
         {
@@ -1975,9 +1977,9 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
         if (num_rank > 0) {
             const dim3 tg((unsigned)vfr::cdiv(Nq * num_rank * NT, 256));
             if (NT == 6)
-                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<6>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0, mw.fallback, mw.wmax);
+                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<6>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0, mw.fallback, mw.wmax, mw.qbound);
             else
-                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<21>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0, mw.fallback, mw.wmax);
+                hipLaunchKernelGGL((vfr::mfma_prep_tab_kernel<21>), tg, dim3(256), 0, st, Nq, num_rank, rank_dist, mw.qmeta, mw.tab, bf16 ? 1 : 0, mw.fallback, mw.wmax, mw.qbound);
         }
         if (k > 0) {
             if (thr_seed)

@@ -63,6 +63,12 @@ struct MfmaArgs {
     const unsigned short *vb;                // bf16 mode: V as bf16 [total_clips][128] (zero padded)
     const float *rv;                         // [1] max norm of the CENTRED clip rows (pre-pass)
     const float *vc, *qc;                    // V - mu [total_clips, D], Q - mu [Nq, D]: the operands of the approximate GEMM
+    unsigned *qbound;                        // [Nq][2] whole-video bounds of the rank keys (zeroed per call, atomicMax by the table pre-pass):
+                                             //   [0] bits of HAB: dmin >= HAB => no moment of the video is counted or ambiguous, for either key
+                                             //   [1] ~bits of BBL: dmax <  BBL => every moment of the video is counted, for both keys
+    int defer_max;                           // whole-video early-out: the rank half of the triangle is skipped when at most this many
+                                             // lanes of the wave are left undecided by HAB / BBL; those lanes are marked ambiguous
+                                             // (re-counted exactly by score_pairs_video_kernel).  < 0: early-out off
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -232,7 +238,8 @@ __global__ __launch_bounds__(256) void mfma_prep_q_kernel(const float *__restric
 template <int NT>
 __global__ __launch_bounds__(256) void mfma_prep_tab_kernel(int64_t Nq, int NR, const float *__restrict__ rank_dist,
                                                             const float4 *__restrict__ qmeta, unsigned *__restrict__ tab,
-                                                            int bf16_mode, int *__restrict__ fallback, unsigned *__restrict__ wmax)
+                                                            int bf16_mode, int *__restrict__ fallback, unsigned *__restrict__ wmax,
+                                                            unsigned *__restrict__ qbound)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= Nq * NR * NT) return;
@@ -260,6 +267,21 @@ __global__ __launch_bounds__(256) void mfma_prep_tab_kernel(int64_t Nq, int NR, 
         if (LOW > LOX) LOW = LOX;
     }
     *reinterpret_cast<uint4 *>(t) = make_uint4(LOX, HIX, LOW, HIW - LOW);
+    // Whole-video bounds (score_mfma_kernel's early-out).  A sum of L approximate distances, each >= dmin, is at least
+    // L dmin (1 - u)^(L - 1) >= L dmin (1 - 21 u); so dmin >= (H / L)(1 + 66 u) with H = the float whose bits are HIW puts every sum of
+    // the level at or above HIW: not counted, not in the window.  Likewise dmax < (Lo / L)(1 - 66 u), Lo = the float of LOW, puts
+    // every sum strictly below LOW: counted.  HAB = max over keys and levels of the first, BBL = min of the second (one pair per
+    // query: "above both keys" / "below both keys"; a video between the keys stays undecided).  The division and the product
+    // round by <= 2 u, the next_up / next_down absorb the rest.
+    if (qbound) {
+        const float H = __uint_as_float(HIW), Lo = __uint_as_float(LOW);
+        float ta = (H / (float)L) * (1.0f + 66.0f * MF_U);
+        ta = ta < __builtin_inff() ? next_up(ta) : ta;
+        float tb = (Lo / (float)L) * (1.0f - 66.0f * MF_U);
+        tb = tb < __builtin_inff() ? (tb > 0.0f ? next_down(tb) : 0.0f) : 3.4028235e38f;
+        atomicMax(qbound + 2 * q, __float_as_uint(ta));
+        atomicMax(qbound + 2 * q + 1, ~__float_as_uint(tb));
+    }
     // The kernel keeps the widths as 10-bit mantissas under one per-query shift (rounded up: a window is never narrowed), so
     // a key deep in the tail -- norms far above the key distance, windows of thousands of ulps -- stays on this path: only
     // its ambiguous pairs cost more.  A key distance so small that no margin exists (delta = inf: the window is the whole
@@ -363,6 +385,10 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
         asm volatile("" ::: "memory");               // one level's table words in flight at a time (not 42 x 4 registers)
     }
     if (!active) thrf = -1.0f;
+    // whole-video bounds of the rank keys (table pre-pass): see MfmaArgs::qbound
+    // (re-read per video -- one 8-byte load from the L1 -- rather than held: the kernel has no two registers to spare)
+    const uint2 *qb_ptr = reinterpret_cast<const uint2 *>(m.qbound) + (active ? qi : 0);
+    const int defer_max = (NR > 0 && m.defer_max >= 0) ? (BF16 ? 0 : m.defer_max) : -1;   // (bf16 mode has no exact re-count: all-decided videos only)
 
 
     // ---- B operand: the clip rows of a tile, k-block by k-block ----
@@ -497,7 +523,7 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
             }
             // approximate distances of this lane's query to the n clips
             float d[NT], sums[NT];
-            float dmin = __builtin_inff();
+            float dmin = __builtin_inff(), dmax = 0.0f;
 #pragma unroll
             for (int c = 0; c < NT; ++c) {
                 int row = r0 + c;
@@ -506,52 +532,91 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
                 const float dd = __builtin_amdgcn_sqrtf(x2 > 0.0f ? x2 : 0.0f);
                 d[c] = c < n ? dd : __builtin_inff();
                 dmin = d[c] < dmin ? d[c] : dmin;
+                if (NR > 0) { const float dr = c < n ? dd : 0.0f; dmax = dr > dmax ? dr : dmax; }
             }
             int amb[NRR] = {0}, cv[NRR] = {0};
             unsigned lvl = 0;
-            unsigned lxn[NRR];                                           // the next level's bounds, requested one level ahead
+            const bool low = !BF16 && (wide || dmin < dfl);
+            // ---- whole-video early-out.  Every moment score is a mean of the video's clip distances, so dmin / dmax decide all
+            // n(n+1)/2 moments at once when they clear the keys' bounds (HAB / BBL: margins derived with the table, mfma_prep_tab_kernel).
+            // Rank half: a lane is DECIDED when its video lies above both keys (count 0) or below both (count n(n+1)/2), or is
+            // marked anyway (`low`).  When at most defer_max lanes of the wave are undecided the rank half of the triangle is not
+            // run: the undecided lanes are marked ambiguous (their pairs are re-counted exactly by score_pairs_video_kernel, like
+            // any pair the windows leave open) -- with keys in the near tail, what a trained model produces, that is almost every
+            // video.  Top-k half: no moment can pass `sum <= thrf L` when dmin (1 - 21 u) > thrf (1 + u): skipped when no lane has one.
+            bool do_rank = NR > 0, do_topk = TOPK;
+            bool und = false, below = false;
+            if (NR > 0 && defer_max >= 0) {
+                asm volatile("" : "+v"(qb_ptr));                         // (keep the load in the loop)
+                const uint2 qb = *qb_ptr;
+                const float hab = __uint_as_float(qb.x), bbl = __uint_as_float(~qb.y);
+                below = active && dmax < bbl;
+                und = !low && !(below || dmin >= hab);
+                if (__builtin_popcountll(__ballot(active && und)) <= defer_max) do_rank = false;
+            }
+            if (TOPK) do_topk = __ballot(dmin <= thrf * 1.00001f) != 0ull;
+            auto triangle = [&](auto rank_c, auto topk_c) {
+                constexpr bool RANK = decltype(rank_c)::value, TK = decltype(topk_c)::value;
+                unsigned lxn[NRR];                                       // the next level's bounds, requested one level ahead
+                if (RANK) {
 #pragma unroll
-            for (int r = 0; r < NR; ++r) lxn[r] = lox_lds[(r * NT) * 64 + lane];
-#pragma unroll
-            for (int L = 1; L <= NT; ++L) {
-                static_assert(NT <= 32, "one 32-bit sign collector per level");
-                unsigned lx[NRR], umin[NRR], below[NRR];
-                const unsigned wd = ((wpk[(L - 1) / 3] >> (10 * ((L - 1) % 3))) & 1023u) << wsh;
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    below[r] = 0u;
-                    lx[r] = lxn[r];
-                    if (L < NT) lxn[r] = lox_lds[(r * NT + L) * 64 + lane];
-                    umin[r] = 0xFFFFFFFFu;
+                    for (int r = 0; r < NR; ++r) lxn[r] = lox_lds[(r * NT) * 64 + lane];
                 }
-                float tmin = __builtin_inff();
 #pragma unroll
-                for (int s = 0; s + L <= NT; ++s) {
-                    const float de = d[s + L - 1];
-                    const float sum = L == 1 ? de : sums[s] + de;
-                    sums[s] = sum;
-                    const unsigned sb = __float_as_uint(sum);
-                    if (TOPK) tmin = __builtin_fminf(sum, tmin);
+                for (int L = 1; L <= NT; ++L) {
+                    static_assert(NT <= 32, "one 32-bit sign collector per level");
+                    unsigned lx[NRR], umin[NRR], below_[NRR];
+                    const unsigned wd = ((wpk[(L - 1) / 3] >> (10 * ((L - 1) % 3))) & 1023u) << wsh;
+                    if (RANK) {
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        const unsigned u = sb - lx[r];
-                        below[r] = __builtin_amdgcn_alignbit(below[r], u, 31);
-                        umin[r] = u < umin[r] ? u : umin[r];
+                        for (int r = 0; r < NR; ++r) {
+                            below_[r] = 0u;
+                            lx[r] = lxn[r];
+                            if (L < NT) lxn[r] = lox_lds[(r * NT + L) * 64 + lane];
+                            umin[r] = 0xFFFFFFFFu;
+                        }
                     }
-                }
+                    float tmin = __builtin_inff();
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    cv[r] += __builtin_popcount(below[r]);
-                    amb[r] += umin[r] < wd ? 1 : 0;
+                    for (int s = 0; s + L <= NT; ++s) {
+                        const float de = d[s + L - 1];
+                        const float sum = L == 1 ? de : sums[s] + de;
+                        sums[s] = sum;
+                        const unsigned sb = __float_as_uint(sum);
+                        if (TK) tmin = __builtin_fminf(sum, tmin);
+                        if (RANK) {
+#pragma unroll
+                            for (int r = 0; r < NR; ++r) {
+                                const unsigned u = sb - lx[r];
+                                below_[r] = __builtin_amdgcn_alignbit(below_[r], u, 31);
+                                umin[r] = u < umin[r] ? u : umin[r];
+                            }
+                        }
+                    }
+                    if (RANK) {
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) {
+                            cv[r] += __builtin_popcount(below_[r]);
+                            amb[r] += umin[r] < wd ? 1 : 0;
+                        }
+                    }
+                    if (TK) lvl = lvl + lvl + (tmin <= thrf * (float)L ? 1u : 0u);
+                    if (RANK && NR == 2) asm volatile("" : "+v"(cv[0]), "+v"(cv[NR > 1 ? 1 : 0]), "+v"(amb[0]), "+v"(amb[NR > 1 ? 1 : 0]), "+v"(lvl));
+                    else asm volatile("" : "+v"(lvl));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (TOPK) lvl = lvl + lvl + (tmin <= thrf * (float)L ? 1u : 0u);
-                if (NR == 2) asm volatile("" : "+v"(cv[0]), "+v"(cv[NR > 1 ? 1 : 0]), "+v"(amb[0]), "+v"(amb[NR > 1 ? 1 : 0]), "+v"(lvl));
-                else asm volatile("" : "+v"(lvl));
-                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (do_rank && do_topk) triangle(std::true_type{}, std::integral_constant<bool, TOPK>{});
+            else if (do_rank) triangle(std::true_type{}, std::false_type{});
+            else if (do_topk) triangle(std::false_type{}, std::integral_constant<bool, TOPK>{});
+            if (NR > 0 && !do_rank) {
+                // decided by the bounds: all n(n+1)/2 moments below both keys, or none; an undecided lane is left to the exact kernel
+                const int Mn = n * (n + 1) / 2;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) { cv[r] = below ? Mn : 0; amb[r] = und ? 1 : 0; }
             }
             if (NR > 0) {
                 unsigned rmask = 0u;
-                const bool low = !BF16 && (wide || dmin < dfl);
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     const bool am = low || amb[r] != 0;

@@ -42,6 +42,7 @@ unsigned *fault_word();                 // vfr_set_fault_word: device-accessible
 int opt_lstm_small();
 int opt_gemm_pp();
 int opt_mfma_min();
+int opt_score_defer();
 
 // ---- launch-site profiler (vfr_set_option("profile", 1)): HIP events recorded on the launch stream
 // around every instrumented launch; vfr_profile_read() turns them into per-site totals after a sync.
