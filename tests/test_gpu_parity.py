@@ -582,6 +582,64 @@ def test_few_queries_scoring_path(vfr, oracle, nq):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("max_n", [6, 21])
+def test_mfma_whole_video_early_out(vfr, oracle, max_n):
+    """The MFMA pre-filter skips the rank half of the moment triangle for a video when the video's smallest / largest clip
+    distance already decides every moment against both rank keys for (nearly) all 64 lanes (`score_defer`: at most that many
+    undecided lanes, which are re-counted exactly; -1 = early-out off).  Rank keys in the near tail (a trained model's regime),
+    mid-distribution, and at the far end (every video BELOW the keys): rank counts and top-k identical for every setting,
+    == the exact kernels, and == `oracle.rank_of` (model/evaluate.py:67-77) on the first queries; bf16 mode: identical across
+    settings (approximate by design, but the early-out must not change what it counts)."""
+    rs = np.random.RandomState(300 + max_n)
+    nv, nq = 500, 150
+    counts = rs.randint(max_n - 1 if max_n == 6 else 3, max_n + 1, nv)
+    counts[rs.randint(nv)] = max_n
+    off = synth.clip_offsets(counts)
+    V = (rs.randn(int(off[-1]), 100) * 0.2).astype(np.float32)
+    src = rs.randint(0, int(off[-1]), nq)
+    Qn = (V[src] + rs.randn(nq, 100).astype(np.float32) * 0.05).astype(np.float32)      # every query next to some clip
+    bank = vfr.VideoBank(dev(V), dev(off.astype(np.int32)))
+    Q = dev(Qn)
+    dense = vfr.score_moments(Q, bank)
+    total = dense.shape[1]
+    order = torch.argsort(dense, dim=1, stable=True)
+    old = vfr.get_option("score_defer")
+    try:
+        for pos in ((3, 40), (total // 2, 11), (total - 1, total - 7)):
+            rd = torch.stack([dense.gather(1, order[:, p:p + 1]).squeeze(1) for p in pos]).contiguous()
+            ri = torch.stack([order[:, p] for p in pos]).contiguous()
+            outs = {}
+            for defer in (-1, 0, 8, 64):
+                vfr.set_option("score_defer", defer)
+                for k in (0, 10):
+                    outs[(defer, k)] = vfr.score_topk(Q, bank, k, rd, ri, mode="mfma")
+                outs[(defer, "bf16")] = vfr.score_topk(Q, bank, 10, rd, ri, mode="bf16")
+            dx, ix, cx = vfr.score_topk(Q, bank, 10, rd, ri, mode="exact")
+            try:                                               # the pass on the caller's query order instead of the difficulty-sorted one
+                vfr.set_option("score_sort", 0)
+                vfr.set_option("score_defer", 8)
+                du, iu, cu = vfr.score_topk(Q, bank, 10, rd, ri, mode="mfma")
+            finally:
+                vfr.set_option("score_sort", 1)
+            assert torch.equal(cu, cx) and torch.equal(iu, ix) and torch.equal(du, dx), (pos, "unsorted")
+            for defer in (-1, 0, 8, 64):
+                for k in (0, 10):
+                    d, i, c = outs[(defer, k)]
+                    assert c.tolist() == [[p] * nq for p in pos], (pos, defer, k)
+                    if k:
+                        assert torch.equal(i, ix) and torch.equal(d, dx), (pos, defer, k)
+                db, ib, cb = outs[(defer, "bf16")]
+                d0, i0, c0 = outs[(-1, "bf16")]
+                assert torch.equal(cb, c0) and torch.equal(ib, i0) and torch.equal(db, d0), (pos, defer, "bf16")
+            m = 12
+            for r in range(2):
+                oc = oracle.rank_of(Qn[:m], V, off.astype(np.int32), rd[r, :m].cpu().numpy().copy(), ri[r, :m].cpu().numpy().copy())
+                assert same(cx[r, :m], oc) and same(outs[(8, 0)][2][r, :m], oc), (pos, r)
+    finally:
+        vfr.set_option("score_defer", old)
+
+
+@pytest.mark.gpu
 def test_mfma_selfcheck_passes_and_can_fail(vfr):
     """What the pre-filter's margins assume about the matrix pipe -- one v_mfma_f32_16x16x4_f32 = four fp32 fmas, k ascending,
     denormals kept -- checked on THIS device against an explicit fmaf chain on adversarial rows (wide exponents, cancelling

@@ -1436,6 +1436,7 @@ struct MfmaWs {
     float *va; float4 *qmeta; unsigned *tab; unsigned *wmax, *qbound; unsigned short *vb; ulonglong2 *amb; int tasks, groups;
     float *mu, *vc, *qc; double *mean_partial; int mean_blocks, mean_rows;
     void *topk; size_t topk_bytes; size_t total;
+    int *perm, *diff; float *Qs, *rds; int64_t *ris, *seeds, *cnts; float *ods; int64_t *ois;
 };
 static MfmaWs carve_mfma(void *base, int64_t Nq, int Nv, int total_clips, int k)
 {
@@ -1466,6 +1467,7 @@ static MfmaWs carve_mfma(void *base, int64_t Nq, int Nv, int total_clips, int k)
     w.cnt_ws = reinterpret_cast<unsigned long long *>(take((size_t)MAX_RANK * Nq * 8));
     w.wmax = reinterpret_cast<unsigned *>(take((size_t)Nq * 4));
     w.qbound = reinterpret_cast<unsigned *>(take((size_t)Nq * 8));
+    w.diff = reinterpret_cast<int *>(take((size_t)Nq * 4));
     w.zero_bytes = off - z0;
     w.qc = reinterpret_cast<float *>(take((size_t)Nq * FAST_D * 4));
     w.qmeta = reinterpret_cast<float4 *>(take((size_t)Nq * 16));
@@ -1474,6 +1476,15 @@ static MfmaWs carve_mfma(void *base, int64_t Nq, int Nv, int total_clips, int k)
     w.amb = reinterpret_cast<ulonglong2 *>(take((size_t)(Nv > 0 ? Nv : 1) * g * sizeof(ulonglong2)));
     w.topk_bytes = carve_topk(nullptr, Nq, Nv, k > 0 ? k + MF_EXTRA : 0).total;
     w.topk = take(w.topk_bytes);
+    // the pass on a permutation of the batch (queries sorted by difficulty, score_mfma.h): sorted inputs, sorted outputs
+    w.perm = reinterpret_cast<int *>(take((size_t)Nq * 4));
+    w.Qs = reinterpret_cast<float *>(take((size_t)Nq * FAST_D * 4));
+    w.rds = reinterpret_cast<float *>(take((size_t)MAX_RANK * Nq * 4));
+    w.ris = reinterpret_cast<int64_t *>(take((size_t)MAX_RANK * Nq * 8));
+    w.seeds = reinterpret_cast<int64_t *>(take((size_t)Nq * 8));
+    w.cnts = reinterpret_cast<int64_t *>(take((size_t)MAX_RANK * Nq * 8));
+    w.ods = reinterpret_cast<float *>(take((size_t)Nq * (k > 0 ? k : 0) * 4));
+    w.ois = reinterpret_cast<int64_t *>(take((size_t)Nq * (k > 0 ? k : 0) * 8));
     w.total = off;
     return w;
 }
@@ -1949,10 +1960,39 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
     vfr::MfmaWs mw = vfr::carve_mfma(workspace, Nq, Nv, total_clips, k);
     vfr::TopkWs w = vfr::carve_topk(mw.topk, Nq, Nv, kp);
     if (hipMemsetAsync(mw.zero_base, 0, mw.zero_bytes, st) != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: hipMemsetAsync failed");
+    // ---- queries sorted by difficulty (score_mfma.h "Query order"): the pass below runs on sorted copies of the per-query inputs
+    // and writes sorted outputs, which the last kernel of the call scatters back (counts added) ----
+    const bool sorted = num_rank > 0 && vfr::opt_score_sort() && Nq >= 128 && Nq <= vfr::SORT_MAX_QUERIES && Nv >= 64 && D == vfr::FAST_D &&
+                        ((((uintptr_t)V) | ((uintptr_t)Q)) & 15) == 0;
+    float *const out_dist_user = out_dist;
+    int64_t *const out_idx_user = out_idx, *const count_lt_user = count_lt;
+    if (sorted) {
+        vfr::ProfScope prof(vfr::SITE_SCORE_PREP, st);
+        if (hipMemsetAsync(mw.cnts, 0, (size_t)num_rank * Nq * 8, st) != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: hipMemsetAsync failed");
+        hipLaunchKernelGGL(vfr::mfma_difficulty_kernel, dim3((unsigned)(vfr::cdiv(Nq, 64) * vfr::SORT_SAMPLE)), dim3(64), 0, st, Q, Nq, V,
+                           clip_offsets, Nv, num_rank, rank_dist, mw.diff);
+        hipLaunchKernelGGL(vfr::mfma_sort_perm_kernel, dim3((unsigned)vfr::cdiv(Nq, 16)), dim3(256), 0, st, mw.diff, (int)Nq, mw.perm);
+        hipLaunchKernelGGL(vfr::mfma_gather_queries_kernel, dim3((unsigned)vfr::cdiv(Nq * vfr::FAST_D, 256)), dim3(256), 0, st, mw.perm, Nq, Q,
+                           num_rank, rank_dist, rank_idx, thr_seed, mw.Qs, mw.rds, mw.ris, mw.seeds);
+        VFR_CHECK_LAUNCH("query sort");
+        Q = mw.Qs; rank_dist = mw.rds; rank_idx = mw.ris; count_lt = mw.cnts;
+        if (thr_seed) thr_seed = mw.seeds;
+        if (k > 0) { out_dist = mw.ods; out_idx = mw.ois; }
+    }
+    auto unsort = [&]() -> int {
+        if (!sorted) return VFR_OK;
+        vfr::ProfScope prof(vfr::SITE_SCORE_FINISH, st);
+        const int per = k > num_rank ? k : num_rank;
+        hipLaunchKernelGGL(vfr::mfma_scatter_results_kernel, dim3((unsigned)vfr::cdiv(Nq * per, 256)), dim3(256), 0, st, mw.perm, Nq, k, num_rank,
+                           mw.ods, mw.ois, mw.cnts, out_dist_user, out_idx_user, count_lt_user);
+        VFR_CHECK_LAUNCH("mfma_scatter_results_kernel");
+        return VFR_OK;
+    };
     vfr::MfmaArgs m{};
     m.va = mw.va; m.qmeta = mw.qmeta; m.tab = mw.tab; m.cnt_ws = mw.cnt_ws; m.amb = mw.amb; m.pairs_total = mw.pairs_total; m.wmax = mw.wmax;
     m.fallback = mw.fallback; m.vb = bf16 ? mw.vb : nullptr; m.rv = mw.rv; m.vc = mw.vc; m.qc = mw.qc;
     m.qbound = mw.qbound; m.defer_max = vfr::opt_score_defer();
+    m.diff = sorted ? mw.diff : nullptr; m.perm = sorted ? mw.perm : nullptr;
     {
         vfr::ProfScope prof(vfr::SITE_SCORE_PREP, st);
         {
@@ -2031,7 +2071,7 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
                                num_rank, Nq, bf16 ? nullptr : mw.fallback, count_lt);
         VFR_CHECK_LAUNCH("mfma finisher");
     }
-    if (bf16) return VFR_OK;
+    if (bf16) return unsort();
     // ---- flagged query groups: the exact kernels, every launch limited to them (returns at once when nothing is flagged) ----
     vfr::TopkWs wx = vfr::carve_topk(mw.topk, Nq, Nv, k);
     vfr::ScoreArgs x{};
@@ -2045,7 +2085,8 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
                                       : hipMemsetAsync(wx.thr, 0xFF, (size_t)Nq * 8, st);
         if (e != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: threshold initialisation failed");
     }
-    return vfr::run_pass(x, wx, thr_seed != nullptr, out_dist, out_idx, nullptr, st);
+    if (int rc = vfr::run_pass(x, wx, thr_seed != nullptr, out_dist, out_idx, nullptr, st)) return rc;
+    return unsort();
 }
 
 

@@ -66,6 +66,7 @@ struct MfmaArgs {
     unsigned *qbound;                        // [Nq][2] whole-video bounds of the rank keys (zeroed per call, atomicMax by the table pre-pass):
                                              //   [0] bits of HAB: dmin >= HAB => no moment of the video is counted or ambiguous, for either key
                                              //   [1] ~bits of BBL: dmax <  BBL => every moment of the video is counted, for both keys
+    const int *diff, *perm;                  // sorted pass (nullable): diff[perm[p]] = difficulty (0 .. SORT_SAMPLE) of the query at sorted position p
     int defer_max;                           // whole-video early-out: the rank half of the triangle is skipped when at most this many
                                              // lanes of the wave are left undecided by HAB / BBL; those lanes are marked ambiguous
                                              // (re-counted exactly by score_pairs_video_kernel).  < 0: early-out off
@@ -291,6 +292,101 @@ __global__ __launch_bounds__(256) void mfma_prep_tab_kernel(int64_t Nq, int NR, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Query order.  The whole-video early-out of score_mfma_kernel is a WAVE decision (64 queries), and query batches are
+// mixtures: with rank keys in the near tail half the queries leave (almost) no video undecided while a quarter leave most
+// of them -- one such query per wave and the wave runs every triangle.  So the pass runs on a permutation of the batch:
+// queries sorted by DIFFICULTY = how many of 64 sample videos (evenly spaced through the bank) the query's smaller rank key
+// leaves undecided (smallest clip distance below the key, largest not).  A heuristic on plain arithmetic (no margins): it
+// only chooses which queries share a wave; every result is computed as before and scattered back to the caller's order.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SORT_MAX_QUERIES = 12288;      // (the rank computation keeps every key in LDS: 48 KB)
+constexpr int SORT_SAMPLE = 64;              // sample videos per query
+// wave-task (query group, sample video): lane = query (its row in registers), the video's clip rows are wave-uniform (scalar
+// loads); a lane for which the video is undecided adds one to its query's count
+__global__ __launch_bounds__(64) void mfma_difficulty_kernel(const float *__restrict__ Q, int64_t Nq, const float *__restrict__ V,
+                                                             const int32_t *__restrict__ clip_off, int Nv, int NR,
+                                                             const float *__restrict__ rank_dist, int *__restrict__ diff)
+{
+    const int lane = threadIdx.x, group = blockIdx.x / SORT_SAMPLE, sv = blockIdx.x % SORT_SAMPLE;
+    const int64_t q = (int64_t)group * 64 + lane;
+    const bool active = q < Nq;
+    const float4 *q4 = reinterpret_cast<const float4 *>(Q + (active ? q : Nq - 1) * FAST_D);
+    float4 qr[FAST_D / 4];
+#pragma unroll
+    for (int j4 = 0; j4 < FAST_D / 4; ++j4) qr[j4] = q4[j4];
+    float x = __builtin_inff();
+    for (int r = 0; r < NR; ++r) { const float y = rank_dist[r * Nq + (active ? q : Nq - 1)]; x = y < x ? y : x; }
+    const int v = (int)((int64_t)sv * Nv / SORT_SAMPLE);
+    const int c0 = clip_off[v], c1 = clip_off[v + 1];
+    float dmin2 = __builtin_inff(), dmax2 = 0.0f;
+    for (int c = c0; c < c1; ++c) {
+        const float *vr = V + (int64_t)c * FAST_D;                       // wave-uniform
+        float acc = 0.0f;
+#pragma unroll
+        for (int j4 = 0; j4 < FAST_D / 4; ++j4) {
+            float t = vr[4 * j4] - qr[j4].x; acc = __builtin_fmaf(t, t, acc);
+            t = vr[4 * j4 + 1] - qr[j4].y; acc = __builtin_fmaf(t, t, acc);
+            t = vr[4 * j4 + 2] - qr[j4].z; acc = __builtin_fmaf(t, t, acc);
+            t = vr[4 * j4 + 3] - qr[j4].w; acc = __builtin_fmaf(t, t, acc);
+        }
+        dmin2 = acc < dmin2 ? acc : dmin2;
+        dmax2 = acc > dmax2 ? acc : dmax2;
+    }
+    const float x2 = x * x;
+    if (active && c1 > c0 && dmin2 < x2 * 1.0002f && !(dmax2 < x2 * 0.9998f)) atomicAdd(diff + q, 1);
+}
+// perm[rank] = q with rank = #{j : diff[j] < diff[q]} + #{j < q : diff[j] == diff[q]} (a stable sort, deterministic); 16 lanes
+// share a query's scan over all keys (LDS)
+__global__ __launch_bounds__(256) void mfma_sort_perm_kernel(const int *__restrict__ diff, int Nq, int *__restrict__ perm)
+{
+    __shared__ int ds[SORT_MAX_QUERIES];
+    for (int i = threadIdx.x; i < Nq; i += 256) ds[i] = diff[i];
+    __syncthreads();
+    const int sub = threadIdx.x & 15, q = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int qq = q < Nq ? q : Nq - 1;
+    const int mine = ds[qq];
+    int rank = 0;
+    for (int j = sub; j < Nq; j += 16) {
+        const int o = ds[j];
+        rank += (o < mine || (o == mine && j < qq)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) rank += __shfl_xor(rank, o, 64);
+    if (q < Nq && sub == 0) perm[rank] = q;
+}
+// sorted copies of the per-query inputs: Qs[p] = Q[perm[p]], rank keys, threshold seeds
+__global__ __launch_bounds__(256) void mfma_gather_queries_kernel(const int *__restrict__ perm, int64_t Nq, const float *__restrict__ Q,
+                                                                  int NR, const float *__restrict__ rank_dist,
+                                                                  const int64_t *__restrict__ rank_idx, const int64_t *__restrict__ seed,
+                                                                  float *__restrict__ Qs, float *__restrict__ rds,
+                                                                  int64_t *__restrict__ ris, int64_t *__restrict__ seeds)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Nq * FAST_D) return;
+    const int64_t p = i / FAST_D;
+    const int kk = (int)(i - p * FAST_D);
+    const int64_t src = perm[p];
+    Qs[i] = Q[src * FAST_D + kk];
+    if (kk < NR) { rds[kk * Nq + p] = rank_dist[kk * Nq + src]; ris[kk * Nq + p] = rank_idx[kk * Nq + src]; }
+    if (kk == MAX_RANK && seed) seeds[p] = seed[src];
+}
+// results back to the caller's order: lists copied, counts ADDED (count_lt accumulates by contract)
+__global__ __launch_bounds__(256) void mfma_scatter_results_kernel(const int *__restrict__ perm, int64_t Nq, int k, int NR,
+                                                                   const float *__restrict__ ods, const int64_t *__restrict__ ois,
+                                                                   const int64_t *__restrict__ cnts, float *__restrict__ out_dist,
+                                                                   int64_t *__restrict__ out_idx, int64_t *__restrict__ count_lt)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per = k > NR ? k : NR;
+    if (i >= Nq * per) return;
+    const int64_t p = i / per;
+    const int j = (int)(i - p * per);
+    const int64_t dst = perm[p];
+    if (j < k) { out_dist[dst * k + j] = ods[p * k + j]; out_idx[dst * k + j] = ois[p * k + j]; }
+    if (j < NR) count_lt[j * Nq + dst] += cnts[j * Nq + p];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // approximate fused kernel.  thread = query for the moment triangle (as score_fast_kernel); the distances of 16-clip
 // column tiles x the wave's 64 queries come from 100 (f32) / 16 (bf16) MFMAs per tile, the accumulator tiles go through a
 // per-wave LDS ring (clip-major rows of 64 queries, 16-byte chunks XOR-swizzled by row so that both the b128 tile writes
@@ -388,7 +484,13 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
     // whole-video bounds of the rank keys (table pre-pass): see MfmaArgs::qbound
     // (re-read per video -- one 8-byte load from the L1 -- rather than held: the kernel has no two registers to spare)
     const uint2 *qb_ptr = reinterpret_cast<const uint2 *>(m.qbound) + (active ? qi : 0);
-    const int defer_max = (NR > 0 && m.defer_max >= 0) ? (BF16 ? 0 : m.defer_max) : -1;   // (bf16 mode has no exact re-count: all-decided videos only)
+    int defer_max = (NR > 0 && m.defer_max >= 0) ? (BF16 ? 0 : m.defer_max) : -1;   // (bf16 mode has no exact re-count: all-decided videos only)
+    if (NR > 0 && defer_max >= 0 && m.diff) {
+        // a wave whose every query left (nearly) all sample videos undecided will not see a decidable video either: it runs without
+        // the test (mid-distribution keys: the whole batch)
+        const int dq = active ? m.diff[m.perm[qi]] : 64;
+        if (__ballot(dq < 63) == 0ull) defer_max = -1;
+    }
 
 
     // ---- B operand: the clip rows of a tile, k-block by k-block ----
