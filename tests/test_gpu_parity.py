@@ -591,7 +591,7 @@ def test_mfma_whole_video_early_out(vfr, oracle, max_n):
     == the exact kernels, and == `oracle.rank_of` (model/evaluate.py:67-77) on the first queries; bf16 mode: identical across
     settings (approximate by design, but the early-out must not change what it counts)."""
     rs = np.random.RandomState(300 + max_n)
-    nv, nq = 500, 150
+    nv, nq = 500, 1100
     counts = rs.randint(max_n - 1 if max_n == 6 else 3, max_n + 1, nv)
     counts[rs.randint(nv)] = max_n
     off = synth.clip_offsets(counts)
@@ -604,6 +604,7 @@ def test_mfma_whole_video_early_out(vfr, oracle, max_n):
     total = dense.shape[1]
     order = torch.argsort(dense, dim=1, stable=True)
     old = vfr.get_option("score_defer")
+    vfr.set_option("score_sort", 2)                # (2: sort whatever the bank size -- the default waits for 2048 videos x 1024 queries)
     try:
         for pos in ((3, 40), (total // 2, 11), (total - 1, total - 7)):
             rd = torch.stack([dense.gather(1, order[:, p:p + 1]).squeeze(1) for p in pos]).contiguous()
@@ -620,7 +621,7 @@ def test_mfma_whole_video_early_out(vfr, oracle, max_n):
                 vfr.set_option("score_defer", 8)
                 du, iu, cu = vfr.score_topk(Q, bank, 10, rd, ri, mode="mfma")
             finally:
-                vfr.set_option("score_sort", 1)
+                vfr.set_option("score_sort", 2)
             assert torch.equal(cu, cx) and torch.equal(iu, ix) and torch.equal(du, dx), (pos, "unsorted")
             for defer in (-1, 0, 8, 64):
                 for k in (0, 10):
@@ -637,6 +638,7 @@ def test_mfma_whole_video_early_out(vfr, oracle, max_n):
                 assert same(cx[r, :m], oc) and same(outs[(8, 0)][2][r, :m], oc), (pos, r)
     finally:
         vfr.set_option("score_defer", old)
+        vfr.set_option("score_sort", 1)
 
 
 @pytest.mark.gpu

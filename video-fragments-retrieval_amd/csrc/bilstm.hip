@@ -1029,8 +1029,7 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
         // 3 .. 64 queries at the model's shape: the whole sequence in one launch on the matrix pipe, weights in registers
         // (lstm_seq_mfma_kernel); every query steps through all T tokens (no sorting, no pad row)
         const size_t gbytes = 16 + (size_t)4 * B * H * sizeof(unsigned long long);
-        if (hipMemsetAsync(w.hg, 0, gbytes, st) != hipSuccess)
-            return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: buffer initialisation failed");
+        if (int rc = vfr::fill_region(w.hg, 0u, gbytes, st)) return rc;
         {
         vfr::ProfScope prof(vfr::SITE_EMBED, st);
         hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(B * T, 256)), dim3(256), 0, st, tokens, B * T, vocab, emb, len_tab,
@@ -1059,9 +1058,10 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
     }
     if (B <= vfr::opt_lstm_small() && B <= 4 && (E % 4) == 0 && (H % 4) == 0 && w.wt && (size_t)4 * (E + H) * 4 <= 48 * 1024) {
         // a handful of queries: every row steps through all T tokens with the vector-chain step (no sorting, no pad row)
-        if (hipMemsetAsync(w.c, 0, (size_t)2 * B * H * sizeof(float), st) != hipSuccess ||
-            hipMemsetAsync(w.hcat, 0, (size_t)B * 2 * H * sizeof(float), st) != hipSuccess)
-            return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: buffer initialisation failed");
+        {
+            const vfr::FillJob jobs[2] = {{w.c, nullptr, (size_t)2 * B * H * sizeof(float), 0u}, {w.hcat, nullptr, (size_t)B * 2 * H * sizeof(float), 0u}};
+            if (int rc = vfr::fill_regions(jobs, 2, st)) return rc;
+        }
         {
         vfr::ProfScope prof(vfr::SITE_EMBED, st);
         hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(B * T, 256)), dim3(256), 0, st, tokens, B * T, vocab, emb, len_tab,
@@ -1074,8 +1074,7 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
         if (vfr::opt_lstm_persist() && B <= 2 && w.hg && H <= 1024 && 2 * E <= 256 && (((uintptr_t)Wfc) & 15) == 0 && seq_lds <= 160 * 1024 && seq_grid <= vfr::device_cu_count() &&
             (B <= 1 ? vfr::seq_lds_admitted(vfr::lstm_seq_small_kernel<1>) : vfr::seq_lds_admitted(vfr::lstm_seq_small_kernel<2>))) {
             const size_t gbytes = 16 + (size_t)4 * B * H * sizeof(unsigned long long);
-            if (hipMemsetAsync(w.hg, 0, gbytes, st) != hipSuccess)
-                return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: buffer initialisation failed");
+            if (int rc = vfr::fill_region(w.hg, 0u, gbytes, st)) return rc;
             // lang_fc rides in the same launch when every output gets a workgroup and the row fits beside the gathered h
             const bool fc_in = D <= seq_grid && (size_t)(1 + (B <= 1 ? 1 : 2)) * 2 * H * sizeof(float) <= seq_lds;
             vfr::SeqLstm a{w.X, {Wih_f, Wih_b}, {Whh_f, Whh_b}, {bih_f, bih_b}, {bhh_f, bhh_b}, w.hg + 2, w.hcat,
@@ -1133,11 +1132,13 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
     }
     const int64_t R = B + 1;                                // GEMM rows: row 0 = all-pad query, then queries by length
     // tokens + one all-pad query -> embeddings of R queries
-    if (hipMemcpyAsync(w.tok_ext, tokens, (size_t)B * T * sizeof(int64_t), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-        hipMemsetAsync(w.tok_ext + (size_t)B * T, 0, (size_t)T * sizeof(int64_t), st) != hipSuccess ||
-        hipMemsetAsync(w.c, 0, (size_t)2 * R * H * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(w.hcat, 0, (size_t)R * 2 * H * sizeof(float), st) != hipSuccess)
-        return vfr::fail(VFR_EHIP, "vfr_bilstm_final_f32: buffer initialisation failed");
+    {
+        const vfr::FillJob jobs[4] = {{w.tok_ext, tokens, (size_t)B * T * sizeof(int64_t), 0u},
+                                      {w.tok_ext + (size_t)B * T, nullptr, (size_t)T * sizeof(int64_t), 0u},
+                                      {w.c, nullptr, (size_t)2 * R * H * sizeof(float), 0u},
+                                      {w.hcat, nullptr, (size_t)R * 2 * H * sizeof(float), 0u}};
+        if (int rc = vfr::fill_regions(jobs, 4, st)) return rc;                     // one launch instead of a copy and three memsets
+    }
     const bool fused = vfr::opt_gemm() != 0 && (E % 4) == 0 && (H % 4) == 0 &&
                        ((((uintptr_t)Wih_f) | ((uintptr_t)Whh_f) | ((uintptr_t)Wih_b) | ((uintptr_t)Whh_b)) & 15) == 0;
     const bool table = fused && vfr::use_vocab_table(B, T, vocab);

@@ -1419,9 +1419,7 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
     a.total_clips = total_clips;
     a.min_clips = min_clips;
     if (Nv > 0 && k > 0) {
-        const hipError_t e = thr_seed ? hipMemcpyAsync(w.thr, thr_seed, (size_t)Nq * 8, hipMemcpyDeviceToDevice, st)
-                                      : hipMemsetAsync(w.thr, 0xFF, (size_t)Nq * 8, st);
-        if (e != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_f32: threshold initialisation failed");
+        if (int rc = thr_seed ? vfr::copy_region(w.thr, thr_seed, (size_t)Nq * 8, st) : vfr::fill_region(w.thr, 0xFFFFFFFFu, (size_t)Nq * 8, st)) return rc;
     }
     return vfr::run_pass(a, w, thr_seed != nullptr, out_dist, out_idx, nullptr, st);
 }
@@ -1959,16 +1957,23 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
     const int kp = k > 0 ? k + vfr::MF_EXTRA : 0;
     vfr::MfmaWs mw = vfr::carve_mfma(workspace, Nq, Nv, total_clips, k);
     vfr::TopkWs w = vfr::carve_topk(mw.topk, Nq, Nv, kp);
-    if (hipMemsetAsync(mw.zero_base, 0, mw.zero_bytes, st) != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: hipMemsetAsync failed");
+    const bool sorted_plan = num_rank > 0 && vfr::opt_score_sort() && Nq >= 1024 && Nq <= vfr::SORT_MAX_QUERIES && (Nv >= 2048 || vfr::opt_score_sort() > 1) &&
+                             Nv >= 64 && D == vfr::FAST_D && ((((uintptr_t)V) | ((uintptr_t)Q)) & 15) == 0;
+    {
+        // one launch: the zeroed region, the +inf thresholds of an unseeded top-k pass, the sorted pass's count buffer
+        const vfr::FillJob jobs[3] = {{mw.zero_base, nullptr, mw.zero_bytes, 0u},
+                                      {w.thr, nullptr, (k > 0 && !thr_seed) ? (size_t)Nq * 8 : 0, 0xFFFFFFFFu},
+                                      {mw.cnts, nullptr, sorted_plan ? (size_t)num_rank * Nq * 8 : 0, 0u}};
+        if (int rc = vfr::fill_regions(jobs, 3, st)) return rc;
+    }
     // ---- queries sorted by difficulty (score_mfma.h "Query order"): the pass below runs on sorted copies of the per-query inputs
     // and writes sorted outputs, which the last kernel of the call scatters back (counts added) ----
-    const bool sorted = num_rank > 0 && vfr::opt_score_sort() && Nq >= 128 && Nq <= vfr::SORT_MAX_QUERIES && Nv >= 64 && D == vfr::FAST_D &&
-                        ((((uintptr_t)V) | ((uintptr_t)Q)) & 15) == 0;
+    // (worth its fixed ~0.08 ms -- sample pass, rank, gather, scatter -- only on a long pass: from ~2000 videos x 1000 queries on)
+    const bool sorted = sorted_plan;
     float *const out_dist_user = out_dist;
     int64_t *const out_idx_user = out_idx, *const count_lt_user = count_lt;
     if (sorted) {
         vfr::ProfScope prof(vfr::SITE_SCORE_PREP, st);
-        if (hipMemsetAsync(mw.cnts, 0, (size_t)num_rank * Nq * 8, st) != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: hipMemsetAsync failed");
         hipLaunchKernelGGL(vfr::mfma_difficulty_kernel, dim3((unsigned)(vfr::cdiv(Nq, 64) * vfr::SORT_SAMPLE)), dim3(64), 0, st, Q, Nq, V,
                            clip_offsets, Nv, num_rank, rank_dist, mw.diff);
         hipLaunchKernelGGL(vfr::mfma_sort_perm_kernel, dim3((unsigned)vfr::cdiv(Nq, 16)), dim3(256), 0, st, mw.diff, (int)Nq, mw.perm);
@@ -2024,8 +2029,7 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
         if (k > 0) {
             if (thr_seed)
                 hipLaunchKernelGGL(vfr::mfma_seed_kernel, dim3((unsigned)vfr::cdiv(Nq, 256)), dim3(256), 0, st, thr_seed, mw.qmeta, Nq, w.thr);
-            else if (hipMemsetAsync(w.thr, 0xFF, (size_t)Nq * 8, st) != hipSuccess)
-                return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: threshold initialisation failed");
+
         }
         VFR_CHECK_LAUNCH("mfma pre-pass");
     }
@@ -2081,9 +2085,7 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
     x.group_mask = mw.fallback;
     x.prof_site = vfr::SITE_SCORE_FALLBACK;
     if (k > 0) {
-        const hipError_t e = thr_seed ? hipMemcpyAsync(wx.thr, thr_seed, (size_t)Nq * 8, hipMemcpyDeviceToDevice, st)
-                                      : hipMemsetAsync(wx.thr, 0xFF, (size_t)Nq * 8, st);
-        if (e != hipSuccess) return vfr::fail(VFR_EHIP, "vfr_score_topk_mfma: threshold initialisation failed");
+        if (int rc = thr_seed ? vfr::copy_region(wx.thr, thr_seed, (size_t)Nq * 8, st) : vfr::fill_region(wx.thr, 0xFFFFFFFFu, (size_t)Nq * 8, st)) return rc;
     }
     if (int rc = vfr::run_pass(x, wx, thr_seed != nullptr, out_dist, out_idx, nullptr, st)) return rc;
     return unsort();

@@ -126,6 +126,50 @@ int opt_mfma_min() { return g_opt_mfma_min; }
 int opt_score_defer() { return g_opt_score_defer; }
 int opt_score_sort() { return g_opt_score_sort; }
 
+struct FillArgs { unsigned *dst[4]; const unsigned *src[4]; unsigned long long words[4]; unsigned value[4]; unsigned long long start[5]; };
+__global__ __launch_bounds__(256) void fill_regions_kernel(FillArgs a)
+{
+    // 16 bytes per thread where the region allows (every region base the library fills is 256-byte aligned; a misaligned or odd
+    // one falls back to words)
+    const unsigned long long total = a.start[4];
+    for (unsigned long long i = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (unsigned long long)gridDim.x * 1024) {
+        const int r = i >= a.start[3] ? 3 : i >= a.start[2] ? 2 : i >= a.start[1] ? 1 : 0;
+        const unsigned long long off = i - a.start[r];
+        unsigned *d = a.dst[r] + off;
+        const unsigned long long left = a.words[r] - off;
+        const bool vec = left >= 4 && (((uintptr_t)d) & 15) == 0 && (!a.src[r] || (((uintptr_t)(a.src[r] + off)) & 15) == 0);
+        if (vec) {
+            const uint4 v = a.src[r] ? *reinterpret_cast<const uint4 *>(a.src[r] + off) : make_uint4(a.value[r], a.value[r], a.value[r], a.value[r]);
+            *reinterpret_cast<uint4 *>(d) = v;
+        } else {
+            for (unsigned long long j = 0; j < (left < 4 ? left : 4); ++j) d[j] = a.src[r] ? a.src[r][off + j] : a.value[r];
+        }
+    }
+}
+int fill_regions(const FillJob *jobs, int n, hipStream_t st)
+{
+    FillArgs a{};
+    unsigned long long total = 0;
+    for (int r = 0; r < 4; ++r) {
+        a.start[r] = total;
+        if (r < n && jobs[r].bytes) {
+            if ((jobs[r].bytes & 3) || (((uintptr_t)jobs[r].dst) & 3) || (((uintptr_t)jobs[r].src) & 3) || !jobs[r].dst)
+                return fail(VFR_EINVAL, "fill_regions: region %d is not a whole number of aligned 4-byte words", r);
+            a.dst[r] = static_cast<unsigned *>(jobs[r].dst); a.src[r] = static_cast<const unsigned *>(jobs[r].src);
+            a.words[r] = jobs[r].bytes / 4;
+            a.value[r] = jobs[r].value32;
+            // regions start at multiples of 4 words in the flat index space, so a thread's 4 words never straddle two regions
+            total += (a.words[r] + 3) / 4 * 4;
+        }
+    }
+    a.start[4] = total;
+    if (total == 0) return VFR_OK;
+    unsigned long long blocks = (total / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_regions_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? VFR_OK : fail(VFR_EHIP, "fill_regions: launch failed");
+}
+
 __global__ void math_probe_kernel(int op, const float *x, const float *y, float *out, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -79,6 +79,14 @@ struct ProfScope {                       // owns its begin event: re-entrant acr
     } while (0)
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Buffer initialisation as ONE kernel launch for up to four regions (each a multiple of 4 bytes, 4-byte aligned): value32 is
+// stored to every word; src != null copies instead.  hipMemsetAsync / hipMemcpyAsync cost ~20 us of stream time apiece on
+// this runtime (a kernel launch ~5), and the entry points issue several per call.
+struct FillJob { void *dst; const void *src; size_t bytes; unsigned value32; };
+int fill_regions(const FillJob *jobs, int n, hipStream_t st);
+inline int fill_region(void *dst, unsigned value32, size_t bytes, hipStream_t st) { const FillJob j{dst, nullptr, bytes, value32}; return fill_regions(&j, 1, st); }
+inline int copy_region(void *dst, const void *src, size_t bytes, hipStream_t st) { const FillJob j{dst, src, bytes, 0u}; return fill_regions(&j, 1, st); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- chain GEMM "NT": out[m][n] = epi( Cin[m][n] | 0  (+)  sum_k A[m][k] * W[n][k] ), one k-ascending
