@@ -623,6 +623,17 @@ def test_mfma_whole_video_early_out(vfr, oracle, max_n):
             finally:
                 vfr.set_option("score_sort", 2)
             assert torch.equal(cu, cx) and torch.equal(iu, ix) and torch.equal(du, dx), (pos, "unsorted")
+            try:                                               # stage B's threshold throughout instead of the candidate histogram's
+                vfr.set_option("score_hist", 0)
+                for kk in (10, 100):
+                    dh, ih, ch = vfr.score_topk(Q, bank, kk, rd, ri, mode="mfma")
+                    vfr.set_option("score_hist", 1)
+                    d1, i1, c1 = vfr.score_topk(Q, bank, kk, rd, ri, mode="mfma")
+                    vfr.set_option("score_hist", 0)
+                    assert torch.equal(ch, c1) and torch.equal(ih, i1) and torch.equal(dh, d1), (pos, kk, "hist")
+                    assert torch.equal(i1[:, :10], ix) and torch.equal(d1[:, :10], dx), (pos, kk, "hist vs exact")
+            finally:
+                vfr.set_option("score_hist", 1)
             for defer in (-1, 0, 8, 64):
                 for k in (0, 10):
                     d, i, c = outs[(defer, k)]

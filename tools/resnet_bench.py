@@ -14,6 +14,8 @@ from vfr_amd import _vfr, synth
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 dev = "cuda:0"
+for _item in filter(None, __import__("os").environ.get("VFR_OPTS", "").split(",")):     # e.g. VFR_OPTS=gemm_small=1
+    _vfr.set_option(_item.split("=")[0], int(_item.split("=")[1]))
 packed = _vfr.resnet_pack(synth.resnet_weights(seed=1), device=dev)
 g = torch.Generator(device=dev); g.manual_seed(0)
 frames = torch.randint(0, 256, (T, 224, 224, 3), generator=g, device=dev, dtype=torch.uint8)

@@ -77,6 +77,9 @@ SIGNATURES = {
     "vfr_vgg_fc7_workspace_bytes": (_sz, [_i32, _i32, _i32, _vp, _i32, _i32]),
     "vfr_resnet_pool_workspace_bytes": (_sz, [_i32, _i32, _i32, _vp, _i32]),
     "vfr_resnet_pool_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _f32, _vp, _vp, _sz, _vp]),
+    "vfr_resnet_folded_bytes": (_sz, [_vp, _i32]),
+    "vfr_resnet_fold_f32": (_i32, [_vp, _i32, _vp, _vp, _f32, _vp, _sz, _vp]),
+    "vfr_resnet_pool_folded_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _sz, _vp, _vp, _sz, _vp]),
     "vfr_vgg_fc7_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
 }
 
@@ -615,7 +618,16 @@ def resnet_pack(state_dict, blocks=RESNET152_BLOCKS, width: int = 64, device="cu
         convs.append(t(state_dict[conv + ".weight"]))
         bns.append(torch.stack([t(state_dict[bn + ".weight"]), t(state_dict[bn + ".bias"]), t(state_dict[bn + ".running_mean"]),
                                 t(state_dict[bn + ".running_var"])]).contiguous())
-    return convs, bns
+    return ResnetPacked((convs, bns))
+
+
+class ResnetPacked(tuple):
+    """``(conv weights, packed BatchNorm tensors)`` as ``resnet_pack`` returns them, plus the folded form ``resnet_pool`` computes
+    once per (blocks, width, eps) and keeps here (``vfr_resnet_fold_f32``): a plain tuple everywhere else."""
+    def __new__(cls, pair):
+        self = super().__new__(cls, pair)
+        self.folded = {}
+        return self
 
 
 def resnet_pool(frames_thwc, packed, blocks=RESNET152_BLOCKS, width: int = 64, eps: float = 1e-5) -> torch.Tensor:
@@ -634,6 +646,21 @@ def resnet_pool(frames_thwc, packed, blocks=RESNET152_BLOCKS, width: int = 64, e
     out = torch.empty((T, 32 * width), dtype=torch.float32, device=fr.device)
     nbytes = lib().vfr_resnet_pool_workspace_bytes(T, H, W, ctypes.cast(bl, ctypes.c_void_p), width)
     ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=fr.device)
+    if isinstance(packed, ResnetPacked):
+        # the model's weights folded once (BatchNorm into the convolutions, tap-major), reused by every later call
+        key = (tuple(int(b) for b in blocks), int(width), float(eps), fr.device)
+        folded = packed.folded.get(key)
+        if folded is None:
+            fb = lib().vfr_resnet_folded_bytes(ctypes.cast(bl, ctypes.c_void_p), width)
+            folded = torch.empty((max(fb, 1),), dtype=torch.uint8, device=fr.device)
+            _check(lib().vfr_resnet_fold_f32(ctypes.cast(bl, ctypes.c_void_p), width, ctypes.cast(wp, ctypes.c_void_p),
+                                             ctypes.cast(bp, ctypes.c_void_p), eps, folded.data_ptr(), folded.numel(), _stream()),
+                   "vfr_resnet_fold_f32")
+            packed.folded[key] = folded
+        _check(lib().vfr_resnet_pool_folded_f32(fr.data_ptr(), T, H, W, ctypes.cast(bl, ctypes.c_void_p), width, folded.data_ptr(),
+                                                folded.numel(), out.data_ptr(), ws.data_ptr(), nbytes, _stream()),
+               "vfr_resnet_pool_folded_f32")
+        return out
     _check(lib().vfr_resnet_pool_f32(fr.data_ptr(), T, H, W, ctypes.cast(bl, ctypes.c_void_p), width, ctypes.cast(wp, ctypes.c_void_p),
                                      ctypes.cast(bp, ctypes.c_void_p), eps, out.data_ptr(), ws.data_ptr(), nbytes, _stream()),
            "vfr_resnet_pool_f32")

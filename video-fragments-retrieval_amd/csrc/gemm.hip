@@ -892,6 +892,50 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             }
         return;
     }
+    // Plain epilogues (bias / residual / ReLU) of 16-byte friendly outputs go through LDS: a lane's accumulator registers are
+    // one column x four rows, so direct stores (and residual loads) are 64-byte row segments -- a 1x1 convolution with a short
+    // K (ResNet's expansion convolutions: K = 64 .. 512, an output and a residual of 4x the input each) then runs at ~1 TB/s on
+    // its epilogue alone.  The tile is parked in the (now idle) staging buffers and leaves as whole rows, 16 bytes per lane:
+    // same values, same order of the additions.
+    if constexpr (!LSTM && !CHALO && !PP) {
+        const bool res = (g.epi & EPI_RES) != 0;
+        const bool vec_epi = !(g.epi & (EPI_POOL2 | EPI_VIS)) && ((g.N | (int)g.ldo | (res ? (int)g.ldr : 0)) & 3) == 0 &&
+                             ((((uintptr_t)g.out) | (res ? (uintptr_t)g.res : (uintptr_t)0)) & 15) == 0;
+        if (vec_epi) {
+            constexpr int CLD = BN + 4, C4 = BN / 4;                      // padded row stride (floats); float4 per tile row
+            static_assert(TBM * CLD <= NBUF * BUF_FLOATS, "the output tile must fit the staging buffers");
+            __syncthreads();                                             // every wave has read its last fragments
+            float *ct = lds;
+#pragma unroll
+            for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ct[(wm * (16 * TI) + ti * 16 + 4 * lq + r) * CLD + wn * 64 + tj * 16 + l15] = acc[ti][tj][r];
+            __syncthreads();
+            for (int idx = tid; idx < TBM * C4; idx += 256) {
+                const int row = idx / C4, c4 = idx - row * C4;
+                const int64_t grow = m0 + row;
+                const int col = n0 + 4 * c4;
+                if (grow >= g.M || col >= g.N) continue;
+                float4 v = *reinterpret_cast<const float4 *>(ct + row * CLD + 4 * c4);
+                if (g.epi & EPI_BIAS2) {
+                    v.x = v.x + (g.bias[col] + g.bias2[col]); v.y = v.y + (g.bias[col + 1] + g.bias2[col + 1]);
+                    v.z = v.z + (g.bias[col + 2] + g.bias2[col + 2]); v.w = v.w + (g.bias[col + 3] + g.bias2[col + 3]);
+                } else if (g.epi & EPI_BIAS) {
+                    v.x = v.x + g.bias[col]; v.y = v.y + g.bias[col + 1]; v.z = v.z + g.bias[col + 2]; v.w = v.w + g.bias[col + 3];
+                }
+                if (res) {
+                    const float4 rr = *reinterpret_cast<const float4 *>(g.res + grow * g.ldr + col);
+                    v.x = v.x + rr.x; v.y = v.y + rr.y; v.z = v.z + rr.z; v.w = v.w + rr.w;
+                }
+                if (g.epi & EPI_RELU) { v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f; v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f; }
+                *reinterpret_cast<float4 *>(g.out + grow * g.ldo + col) = v;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -938,6 +982,9 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
 
 template <bool VEC, int MI = 2>
 __global__ __launch_bounds__(256, (VFR_GEMM_NBUF == 1 || MI <= 1) ? 3 : 2) void gemm_nt_mfma(GemmArgs g) { gemm_nt_mfma_body<VEC, false, false, MI>(g); }
+
+// dense operands with N <= 64 (ResNet's stem and layer1 1x1 convolutions): 128 x 64 tiles, no MFMA spent on absent columns
+__global__ __launch_bounds__(256, 3) void gemm_nt_mfma_narrow(GemmArgs g) { gemm_nt_mfma_body<true, false, false, 1, false, true>(g); }
 
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_nt_mfma_pair(GemmPair gp)
@@ -1199,8 +1246,17 @@ int gemm_nt(const GemmArgs &g, hipStream_t st)
         VFR_CHECK_LAUNCH("gemm_nt_mfma<64>");
         return VFR_OK;
     }
+    if (vec && g.N <= 64) {
+        hipLaunchKernelGGL(gemm_nt_mfma_narrow, dim3(grid.x, 1), dim3(256), 0, st, g);
+        VFR_CHECK_LAUNCH("gemm_nt_mfma_narrow");
+        return VFR_OK;
+    }
     const bool pp = opt_gemm_pp() && (g.K % MBK) == 0 && g.K >= 2 * MBK;
-    if (opt_gemm_small() == 1) {             // experiment: 64-row tiles (three workgroups per CU) for the large GEMMs too
+    // Short chains (K <= 2048: ResNet's 1x1 convolutions, the clip encoder's output layer): a 128-row tile's prologue and
+    // epilogue weigh as much as its few K-tiles, and three 64-row workgroups per CU cover them better than two 128-row ones
+    // (tools/resnet_layers.py: the expansion convolutions 179 -> 148 us, the whole ResNet-152 stack 33.9 -> 31.6 ms).  Long
+    // chains (the clip encoder's K = 4096) keep the 128-row tiles (123-127 TF against 117-120).
+    if (opt_gemm_small() == 1 || (opt_gemm_small() == 0 && g.K <= 2048)) {
         const unsigned gx64 = (unsigned)cdiv(g.M, 64);
         GemmArgs gx = g;
         const bool xcd = grid.y > 1 && grid.y <= 16 && gx64 >= 64;

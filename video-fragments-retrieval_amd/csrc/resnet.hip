@@ -19,18 +19,35 @@
 
 namespace vfr {
 
-// w [Cout, Cin, KH, KW] + bn [4][Cout] (gamma, b, mean, var) -> wf [Cout][KH*KW*Cinp] tap-major (zero for ci >= Cin), beta [Cout]
-__global__ __launch_bounds__(256) void bn_fold_repack_kernel(const float *__restrict__ w, const float *__restrict__ bn, int Cout, int Cin,
-                                                             int Cinp, int taps, float eps, float *__restrict__ wf, float *__restrict__ beta)
+// w [Cout, Cin, KH, KW] + bn [4][Cout] (gamma, b, mean, var) -> wf [Cout][KH*KW*Cinp] tap-major (zero for ci >= Cin), beta [Cout],
+// for up to FOLD_BATCH convolutions in ONE launch (a ResNet-152 has 155: one launch each was 1.2 ms of launches for 0.1 ms of
+// work): blockIdx.y = convolution (its fields are wave-uniform: scalar loads from the kernel arguments), blockIdx.x strides
+// over its elements
+constexpr int FOLD_BATCH = 64;
+struct FoldBatch {
+    const float *w[FOLD_BATCH], *bn[FOLD_BATCH];
+    float *wf[FOLD_BATCH], *beta[FOLD_BATCH];
+    unsigned short cout[FOLD_BATCH], cin[FOLD_BATCH], cinp[FOLD_BATCH], taps[FOLD_BATCH];
+    int n;
+    float eps;
+};
+__global__ __launch_bounds__(256) void bn_fold_repack_batch_kernel(FoldBatch b)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int K = taps * Cinp;
-    if (i >= (int64_t)Cout * K) return;
-    const int co = (int)(i / K), k = (int)(i - (int64_t)co * K), tap = k / Cinp, ci = k - tap * Cinp;
-    const float invstd = 1.0f / __builtin_sqrtf(bn[3 * Cout + co] + eps);
-    const float alpha = bn[co] * invstd;
-    wf[i] = ci < Cin ? w[((int64_t)co * Cin + ci) * taps + tap] * alpha : 0.0f;
-    if (k == 0) beta[co] = __builtin_fmaf(-bn[2 * Cout + co], alpha, bn[Cout + co]);
+    const int j = blockIdx.y;
+    const int Cout = b.cout[j], Cin = b.cin[j], Cinp = b.cinp[j], taps = b.taps[j], K = taps * Cinp;
+    const float *__restrict__ w = b.w[j], *__restrict__ bn = b.bn[j];
+    float *__restrict__ wf = b.wf[j], *__restrict__ beta = b.beta[j];
+    // a block takes whole output channels: alpha once per channel (wave-uniform), no per-element division
+    for (int co = blockIdx.x; co < Cout; co += gridDim.x) {
+        const float invstd = 1.0f / __builtin_sqrtf(bn[3 * Cout + co] + b.eps);
+        const float alpha = bn[co] * invstd;
+        if (threadIdx.x == 0) beta[co] = __builtin_fmaf(-bn[2 * Cout + co], alpha, bn[Cout + co]);
+        const float *wr = w + (int64_t)co * Cin * taps;
+        float *dst = wf + (int64_t)co * K;
+        for (int tap = 0; tap < taps; ++tap)
+            for (int ci = threadIdx.x; ci < Cinp; ci += 256)
+                dst[tap * Cinp + ci] = ci < Cin ? wr[(int64_t)ci * taps + tap] * alpha : 0.0f;
+    }
 }
 
 // NHWC x [B, H, W, C] (C % 4 == 0) -> col [B*Ho*Wo, KH*KW*C]: column (tap, c) of output pixel (n, oy, ox) = x[n][oy*s+ky-p][ox*s+kx-p][c]
@@ -174,46 +191,67 @@ size_t vfr_resnet_pool_workspace_bytes(int T, int H, int W, const int *blocks_ho
            vfr::align_up(p.wf_elems * sizeof(float), 256) + vfr::align_up(p.beta_elems * sizeof(float), 256);
 }
 
-int vfr_resnet_pool_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *blocks_host, int width,
-                        const float *const *conv_w_host, const float *const *bn_host, float bn_eps, float *out, void *workspace,
-                        size_t workspace_bytes, vfr_stream_t stream)
+size_t vfr_resnet_folded_bytes(const int *blocks_host, int width)
 {
-    using namespace vfr;
-    VFR_REQUIRE(frames_thwc && blocks_host && conv_w_host && bn_host && out && T >= 0 && H > 0 && W > 0 && width > 0, VFR_EINVAL,
-                "vfr_resnet_pool_f32: bad argument");
-    if (T == 0) return VFR_OK;
-    const int chunk = resnet_chunk(T);
-    ResPlan p = plan_resnet(chunk, H, W, blocks_host, width);
-    VFR_REQUIRE(p.ok, VFR_EUNSUPPORTED, "vfr_resnet_pool_f32: needs a width that is a multiple of 4, positive block counts and frames of at least 32x32");
-    VFR_REQUIRE(workspace && workspace_bytes >= vfr_resnet_pool_workspace_bytes(T, H, W, blocks_host, width), VFR_EWORKSPACE,
-                "vfr_resnet_pool_f32: workspace %zu < %zu bytes", workspace_bytes, vfr_resnet_pool_workspace_bytes(T, H, W, blocks_host, width));
-    hipStream_t st = as_stream(stream);
-    char *base = static_cast<char *>(workspace);
+    if (!blocks_host || width <= 0) return 0;
+    vfr::ResPlan p = vfr::plan_resnet(1, 224, 224, blocks_host, width);
+    return vfr::align_up(p.wf_elems * sizeof(float), 256) + vfr::align_up(p.beta_elems * sizeof(float), 256);
+}
+
+}  // extern "C"
+
+namespace vfr {
+
+// fold + repack every convolution of the plan into [wf region | beta region] at `folded` (FOLD_BATCH convolutions per launch)
+static int resnet_fold(const ResPlan &p, const float *const *conv_w_host, const float *const *bn_host, float bn_eps, void *folded,
+                       std::vector<float *> &wf, std::vector<float *> &beta, bool launch, hipStream_t st)
+{
+    float *wq = static_cast<float *>(folded);
+    float *bq = reinterpret_cast<float *>(static_cast<char *>(folded) + align_up(p.wf_elems * sizeof(float), 256));
+    wf.resize(p.convs.size()); beta.resize(p.convs.size());
+    FoldBatch fb{};
+    fb.eps = bn_eps;
+    unsigned most = 0;
+    auto flush = [&]() {
+        if (fb.n == 0) return;
+        unsigned blocks = most;                                   // output channels of the widest convolution, capped
+        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+        hipLaunchKernelGGL(bn_fold_repack_batch_kernel, dim3(blocks, (unsigned)fb.n), dim3(256), 0, st, fb);
+        fb.n = 0; most = 0;
+    };
+    for (size_t i = 0; i < p.convs.size(); ++i) {
+        const ResConv &c = p.convs[i];
+        const int cinp = c.cin < 4 ? 4 : c.cin, taps = c.k * c.k;
+        const int64_t n = (int64_t)c.cout * taps * cinp;
+        wf[i] = wq; beta[i] = bq;
+        if (launch) {
+            VFR_REQUIRE(conv_w_host[i] && bn_host[i], VFR_EINVAL, "vfr_resnet: null weight pointer for convolution %zu", i);
+            VFR_REQUIRE(n < (1ll << 31) && c.cout < 65536 && cinp < 65536, VFR_EUNSUPPORTED, "vfr_resnet: convolution %zu is too large", i);
+            if (fb.n == FOLD_BATCH) flush();
+            const int j = fb.n++;
+            fb.w[j] = conv_w_host[i]; fb.bn[j] = bn_host[i]; fb.wf[j] = wq; fb.beta[j] = bq;
+            fb.cout[j] = (unsigned short)c.cout; fb.cin[j] = (unsigned short)c.cin; fb.cinp[j] = (unsigned short)cinp; fb.taps[j] = (unsigned short)taps;
+            most = (unsigned)c.cout > most ? (unsigned)c.cout : most;
+        }
+        wq += align_up((size_t)n, 64); bq += align_up((size_t)c.cout, 64);
+    }
+    if (launch) {
+        ProfScope prof(SITE_REPACK, st);
+        flush();
+        VFR_CHECK_LAUNCH("bn_fold_repack_batch_kernel");
+    }
+    return VFR_OK;
+}
+
+// the stack on folded weights: wf / beta per convolution; workspace = [x0 | 4 activation buffers | im2col buffer]
+static int resnet_run(const ResPlan &p, const uint8_t *frames_thwc, int T, int chunk, int H, int W, const int *blocks_host, int width,
+                      const std::vector<float *> &wf, const std::vector<float *> &beta, float *out, char *base, hipStream_t st)
+{
     auto carve = [&](size_t bytes) { char *q = base; base += align_up(bytes, 256); return reinterpret_cast<float *>(q); };
     float *x0 = carve((size_t)chunk * H * W * 4 * sizeof(float));
     float *buf[4];
     for (int i = 0; i < 4; ++i) buf[i] = carve(p.act_elems * sizeof(float));
     float *col = carve(p.col_elems * sizeof(float));
-    float *wf_base = carve(p.wf_elems * sizeof(float));
-    float *beta_base = carve(p.beta_elems * sizeof(float));
-
-    // fold + repack every convolution once per call
-    std::vector<float *> wf(p.convs.size()), beta(p.convs.size());
-    {
-        ProfScope prof(SITE_REPACK, st);
-        float *wq = wf_base, *bq = beta_base;
-        for (size_t i = 0; i < p.convs.size(); ++i) {
-            const ResConv &c = p.convs[i];
-            const int cinp = c.cin < 4 ? 4 : c.cin, taps = c.k * c.k;
-            const int64_t n = (int64_t)c.cout * taps * cinp;
-            VFR_REQUIRE(conv_w_host[i] && bn_host[i], VFR_EINVAL, "vfr_resnet_pool_f32: null weight pointer for convolution %zu", i);
-            hipLaunchKernelGGL(bn_fold_repack_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, conv_w_host[i], bn_host[i], c.cout, c.cin,
-                               cinp, taps, bn_eps, wq, bq);
-            wf[i] = wq; beta[i] = bq;
-            wq += align_up((size_t)n, 64); bq += align_up((size_t)c.cout, 64);
-        }
-    }
-    VFR_CHECK_LAUNCH("bn_fold_repack_kernel");
 
     // one convolution: x [bt, h, w, cinp] -> y [bt, ho, wo, cout]
     auto conv = [&](size_t ci, const float *x, int bt, int h, int w, float *y, const float *res, bool relu) -> int {
@@ -284,6 +322,65 @@ int vfr_resnet_pool_f32(const uint8_t *frames_thwc, int T, int H, int W, const i
         VFR_CHECK_LAUNCH("resnet stack");
     }
     return VFR_OK;
+}
+
+}  // namespace vfr
+
+extern "C" {
+
+int vfr_resnet_fold_f32(const int *blocks_host, int width, const float *const *conv_w_host, const float *const *bn_host, float bn_eps,
+                        void *folded, size_t folded_bytes, vfr_stream_t stream)
+{
+    using namespace vfr;
+    VFR_REQUIRE(blocks_host && conv_w_host && bn_host && folded && width > 0, VFR_EINVAL, "vfr_resnet_fold_f32: bad argument");
+    ResPlan p = plan_resnet(1, 224, 224, blocks_host, width);
+    VFR_REQUIRE(p.ok, VFR_EUNSUPPORTED, "vfr_resnet_fold_f32: needs a width that is a multiple of 4 and positive block counts");
+    VFR_REQUIRE(folded_bytes >= vfr_resnet_folded_bytes(blocks_host, width), VFR_EWORKSPACE, "vfr_resnet_fold_f32: buffer %zu < %zu bytes",
+                folded_bytes, vfr_resnet_folded_bytes(blocks_host, width));
+    std::vector<float *> wf, beta;
+    return resnet_fold(p, conv_w_host, bn_host, bn_eps, folded, wf, beta, true, as_stream(stream));
+}
+
+int vfr_resnet_pool_folded_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *blocks_host, int width, const void *folded,
+                               size_t folded_bytes, float *out, void *workspace, size_t workspace_bytes, vfr_stream_t stream)
+{
+    using namespace vfr;
+    VFR_REQUIRE(frames_thwc && blocks_host && folded && out && T >= 0 && H > 0 && W > 0 && width > 0, VFR_EINVAL,
+                "vfr_resnet_pool_folded_f32: bad argument");
+    if (T == 0) return VFR_OK;
+    const int chunk = resnet_chunk(T);
+    ResPlan p = plan_resnet(chunk, H, W, blocks_host, width);
+    VFR_REQUIRE(p.ok, VFR_EUNSUPPORTED, "vfr_resnet_pool_folded_f32: needs a width that is a multiple of 4, positive block counts and frames of at least 32x32");
+    VFR_REQUIRE(folded_bytes >= vfr_resnet_folded_bytes(blocks_host, width), VFR_EWORKSPACE, "vfr_resnet_pool_folded_f32: folded buffer %zu < %zu bytes",
+                folded_bytes, vfr_resnet_folded_bytes(blocks_host, width));
+    VFR_REQUIRE(workspace && workspace_bytes >= vfr_resnet_pool_workspace_bytes(T, H, W, blocks_host, width), VFR_EWORKSPACE,
+                "vfr_resnet_pool_folded_f32: workspace %zu < %zu bytes", workspace_bytes, vfr_resnet_pool_workspace_bytes(T, H, W, blocks_host, width));
+    std::vector<float *> wf, beta;
+    if (int rc = resnet_fold(p, nullptr, nullptr, 0.0f, const_cast<void *>(folded), wf, beta, false, as_stream(stream))) return rc;
+    return resnet_run(p, frames_thwc, T, chunk, H, W, blocks_host, width, wf, beta, out, static_cast<char *>(workspace), as_stream(stream));
+}
+
+int vfr_resnet_pool_f32(const uint8_t *frames_thwc, int T, int H, int W, const int *blocks_host, int width,
+                        const float *const *conv_w_host, const float *const *bn_host, float bn_eps, float *out, void *workspace,
+                        size_t workspace_bytes, vfr_stream_t stream)
+{
+    using namespace vfr;
+    VFR_REQUIRE(frames_thwc && blocks_host && conv_w_host && bn_host && out && T >= 0 && H > 0 && W > 0 && width > 0, VFR_EINVAL,
+                "vfr_resnet_pool_f32: bad argument");
+    if (T == 0) return VFR_OK;
+    const int chunk = resnet_chunk(T);
+    ResPlan p = plan_resnet(chunk, H, W, blocks_host, width);
+    VFR_REQUIRE(p.ok, VFR_EUNSUPPORTED, "vfr_resnet_pool_f32: needs a width that is a multiple of 4, positive block counts and frames of at least 32x32");
+    VFR_REQUIRE(workspace && workspace_bytes >= vfr_resnet_pool_workspace_bytes(T, H, W, blocks_host, width), VFR_EWORKSPACE,
+                "vfr_resnet_pool_f32: workspace %zu < %zu bytes", workspace_bytes, vfr_resnet_pool_workspace_bytes(T, H, W, blocks_host, width));
+    hipStream_t st = as_stream(stream);
+    // the folded weights live at the END of the workspace (fold + repack of every convolution, every call: callers that keep the
+    // model resident fold once with vfr_resnet_fold_f32 and use vfr_resnet_pool_folded_f32)
+    const size_t fbytes = vfr_resnet_folded_bytes(blocks_host, width);
+    char *fold_at = static_cast<char *>(workspace) + vfr_resnet_pool_workspace_bytes(T, H, W, blocks_host, width) - fbytes;
+    std::vector<float *> wf, beta;
+    if (int rc = resnet_fold(p, conv_w_host, bn_host, bn_eps, fold_at, wf, beta, true, st)) return rc;
+    return resnet_run(p, frames_thwc, T, chunk, H, W, blocks_host, width, wf, beta, out, static_cast<char *>(workspace), st);
 }
 
 }  // extern "C"

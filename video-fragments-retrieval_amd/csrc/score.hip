@@ -800,7 +800,8 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
                                                                unsigned long long *__restrict__ thr_seed,
                                                                float *__restrict__ out_dist,
                                                                int64_t *__restrict__ out_idx, int seed_inclusive,
-                                                               const int *__restrict__ group_mask)
+                                                               const int *__restrict__ group_mask,
+                                                               unsigned *__restrict__ hist = nullptr, uint2 *__restrict__ hrange = nullptr)
 {
     constexpr int CAP = KPL * 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -882,6 +883,25 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
     if (extra)                            // a pre-sorted k-list per query (the threshold ladder's previous stage), KEY_MAX padded
         for (int off = 0; off < k; off += 64) append(off + lane < k ? extra[q * k + off + lane] : KEY_MAX, off + lane < k);
     sort_pool(true);
+    if (hist) {
+        // the top-k threshold histogram of the main launch (score_mfma.h): MF_HBINS bins of score BITS, a power-of-two wide, from
+        // this list's best key up to its k-th; the list's keys are its first entries
+        const unsigned long long kb = key_at<KPL>(key, 0), kk = key_at<KPL>(key, k - 1);
+        if (kk != KEY_MAX) {
+            const unsigned lob = (unsigned)(kb >> 32), span = (unsigned)(kk >> 32) - lob + 1u;
+            unsigned shift = 0u;
+            while ((span >> shift) > (unsigned)(MF_HBINS - 2)) ++shift;      // the k-th key falls in a bin below the last
+            if (lane == 0) hrange[q] = make_uint2(lob, shift + 1u);
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                const int e = i * 64 + lane;
+                if (e < k && key[i] != KEY_MAX) {
+                    const unsigned bin = ((unsigned)(key[i] >> 32) - lob) >> shift;
+                    atomicAdd(hist + (size_t)q * MF_HBINS + (bin < (unsigned)(MF_HBINS - 1) ? bin : (unsigned)(MF_HBINS - 1)), 1u);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < KPL; ++i) {
         int e = i * 64 + lane;
@@ -1282,14 +1302,15 @@ static int run_pass(ScoreArgs a, const TopkWs &w, bool seeded, float *out_dist, 
     int cap_t = 0, cap_pre = 0;
     const unsigned long long *extra = nullptr;
     auto merge = [&](const unsigned long long *buf, const int *cnt, int chunks, int capt, const unsigned long long *ex,
-                     unsigned long long *okeys, unsigned long long *seed, float *od, int64_t *oi, int seed_incl = 0) {
+                     unsigned long long *okeys, unsigned long long *seed, float *od, int64_t *oi, int seed_incl = 0,
+                     unsigned *hist = nullptr, uint2 *hrange = nullptr) {
         dim3 grid((unsigned)cdiv(Nq, 4)), block(256);
         if (kpl == 4)
             hipLaunchKernelGGL((topk_merge_tasks_kernel<4>), grid, block, 0, st, buf, cnt, a.num_groups, chunks, Nq, k,
-                               capt, ex, okeys, seed, od, oi, seed_incl, a.group_mask);
+                               capt, ex, okeys, seed, od, oi, seed_incl, a.group_mask, hist, hrange);
         else
             hipLaunchKernelGGL((topk_merge_tasks_kernel<8>), grid, block, 0, st, buf, cnt, a.num_groups, chunks, Nq, k,
-                               capt, ex, okeys, seed, od, oi, seed_incl, a.group_mask);
+                               capt, ex, okeys, seed, od, oi, seed_incl, a.group_mask, hist, hrange);
     };
     if (Nv > 0) {
         // threshold ladder (see PRE_VIDEOS).  Stage A needs no seed and runs for every bank size (a 32-video sample shard is
@@ -1327,7 +1348,9 @@ static int run_pass(ScoreArgs a, const TopkWs &w, bool seeded, float *out_dist, 
             if (int rc = launch_score<1>(b, kpl, st, &cap_t)) return rc;
             {
                 ProfScope prof(SITE_TOPK_MERGE, st);
-                merge(w.buf, w.cnt, b.num_chunks, cap_t, extra, w.pre_keys2, w.thr, nullptr, nullptr);
+                // (MFMA pre-filter: the merged list also seeds the main launch's threshold histogram)
+                merge(w.buf, w.cnt, b.num_chunks, cap_t, extra, w.pre_keys2, w.thr, nullptr, nullptr, 0,
+                      a.mf_host ? a.mf_host->hist : nullptr, a.mf_host ? a.mf_host->hrange : nullptr);
             }
             VFR_CHECK_LAUNCH("topk_merge_tasks_kernel(B)");
             extra = w.pre_keys2;
@@ -1434,7 +1457,7 @@ struct MfmaWs {
     float *va; float4 *qmeta; unsigned *tab; unsigned *wmax, *qbound; unsigned short *vb; ulonglong2 *amb; int tasks, groups;
     float *mu, *vc, *qc; double *mean_partial; int mean_blocks, mean_rows;
     void *topk; size_t topk_bytes; size_t total;
-    int *perm, *diff; float *Qs, *rds; int64_t *ris, *seeds, *cnts; float *ods; int64_t *ois;
+    int *perm, *diff; unsigned *hist; uint2 *hrange; float *Qs, *rds; int64_t *ris, *seeds, *cnts; float *ods; int64_t *ois;
 };
 static MfmaWs carve_mfma(void *base, int64_t Nq, int Nv, int total_clips, int k)
 {
@@ -1466,6 +1489,8 @@ static MfmaWs carve_mfma(void *base, int64_t Nq, int Nv, int total_clips, int k)
     w.wmax = reinterpret_cast<unsigned *>(take((size_t)Nq * 4));
     w.qbound = reinterpret_cast<unsigned *>(take((size_t)Nq * 8));
     w.diff = reinterpret_cast<int *>(take((size_t)Nq * 4));
+    w.hist = reinterpret_cast<unsigned *>(take(k > 0 ? (size_t)Nq * MF_HBINS * 4 : 0));
+    w.hrange = reinterpret_cast<uint2 *>(take(k > 0 ? (size_t)Nq * 8 : 0));
     w.zero_bytes = off - z0;
     w.qc = reinterpret_cast<float *>(take((size_t)Nq * FAST_D * 4));
     w.qmeta = reinterpret_cast<float4 *>(take((size_t)Nq * 16));
@@ -1998,6 +2023,7 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
     m.fallback = mw.fallback; m.vb = bf16 ? mw.vb : nullptr; m.rv = mw.rv; m.vc = mw.vc; m.qc = mw.qc;
     m.qbound = mw.qbound; m.defer_max = vfr::opt_score_defer();
     m.diff = sorted ? mw.diff : nullptr; m.perm = sorted ? mw.perm : nullptr;
+    m.hist = (k > 0 && vfr::opt_score_hist()) ? mw.hist : nullptr; m.hrange = mw.hrange;
     {
         vfr::ProfScope prof(vfr::SITE_SCORE_PREP, st);
         {

@@ -46,6 +46,7 @@
 constexpr int MF_EXTRA = 28;                 // k' = k + MF_EXTRA candidates by approximate key
 constexpr float MF_U = 5.9604645e-8f;        // 2^-24
 constexpr unsigned MF_WIDTH_MAX = 1u << 28;  // window widths (ulps of the sum) the kernel's shifted 10-bit fields hold
+constexpr int MF_HBINS = 32;                 // bins of the top-k threshold histogram (below)
 constexpr int MF_TAB = 4;                    // table words per (query, key, L): LO, HI (exact, exclusive bit bounds), LO wide, width
 #define MF_RING_ROWS(NT) ((NT) > 6 ? 38 : 32)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -66,6 +67,8 @@ struct MfmaArgs {
     unsigned *qbound;                        // [Nq][2] whole-video bounds of the rank keys (zeroed per call, atomicMax by the table pre-pass):
                                              //   [0] bits of HAB: dmin >= HAB => no moment of the video is counted or ambiguous, for either key
                                              //   [1] ~bits of BBL: dmax <  BBL => every moment of the video is counted, for both keys
+    unsigned *hist;                          // [Nq][MF_HBINS] top-k threshold histogram (nullable; zeroed per call): counts of candidate keys by score
+    uint2 *hrange;                           // [Nq] {score bits of bin 0's lower edge, 1 + log2(bin width in bits)}; .y == 0: histogram not in use for the query
     const int *diff, *perm;                  // sorted pass (nullable): diff[perm[p]] = difficulty (0 .. SORT_SAMPLE) of the query at sorted position p
     int defer_max;                           // whole-video early-out: the rank half of the triangle is skipped when at most this many
                                              // lanes of the wave are left undecided by HAB / BBL; those lanes are marked ambiguous
@@ -481,9 +484,40 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
         asm volatile("" ::: "memory");               // one level's table words in flight at a time (not 42 x 4 registers)
     }
     if (!active) thrf = -1.0f;
+    // ---- top-k threshold from the candidate histogram (main launch of the ladder only).  Stage B's merge leaves, per query, its
+    // k' best keys spread over MF_HBINS bins of score bits between its best and its k'-th key, and every candidate this launch
+    // appends adds one to its bin.  A task that starts later reads the bins: if bins 0 .. b already hold k' keys, every one of
+    // the final k' best keys lies below bin b's upper edge -- a valid threshold (k' real keys bound the k'-th best), tighter than
+    // stage B's with every task that has finished.  Counts are read while others add to them: a late count only loosens. ----
+    bool hon = false;                                                     // (the range is re-read where a candidate is counted: no registers to spare)
+    if (TOPK && m.hist && !a.keep_all && a.level_cap == 0 && active) {
+        const uint2 hr = m.hrange[qi];
+        if (hr.y != 0u) {
+            hon = true;
+            const unsigned hlob = hr.x, hshift = hr.y - 1u;
+            const uint4 *hb = reinterpret_cast<const uint4 *>(m.hist + (size_t)qi * MF_HBINS);
+            unsigned cum = 0u, edge_bin = MF_HBINS;
+#pragma unroll
+            for (int i = 0; i < MF_HBINS / 4; ++i) {
+                const uint4 c4 = hb[i];
+                const unsigned cs[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    cum += cs[jx];
+                    if (cum >= (unsigned)a.k && edge_bin == MF_HBINS) edge_bin = (unsigned)(4 * i + jx);
+                }
+            }
+            if (edge_bin < MF_HBINS - 1) {                                 // (the last bin also holds everything above the range: no edge)
+                const unsigned long long tc = (unsigned long long)(hlob + ((edge_bin + 1u) << hshift)) << 32;
+                if (tc < thr) {
+                    thr = tc;
+                    __hip_atomic_fetch_min(a.thr_global + qi, thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
     // whole-video bounds of the rank keys (table pre-pass): see MfmaArgs::qbound
     // (re-read per video -- one 8-byte load from the L1 -- rather than held: the kernel has no two registers to spare)
-    const uint2 *qb_ptr = reinterpret_cast<const uint2 *>(m.qbound) + (active ? qi : 0);
     int defer_max = (NR > 0 && m.defer_max >= 0) ? (BF16 ? 0 : m.defer_max) : -1;   // (bf16 mode has no exact re-count: all-decided videos only)
     if (NR > 0 && defer_max >= 0 && m.diff) {
         // a wave whose every query left (nearly) all sample videos undecided will not see a decidable video either: it runs without
@@ -649,8 +683,11 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
             bool do_rank = NR > 0, do_topk = TOPK;
             bool und = false, below = false;
             if (NR > 0 && defer_max >= 0) {
-                asm volatile("" : "+v"(qb_ptr));                         // (keep the load in the loop)
-                const uint2 qb = *qb_ptr;
+                // (address rebuilt from the lane id every time: a held pointer would cost two registers the kernel does not have)
+                unsigned qx = (unsigned)(group * 64 + lane);
+                asm volatile("" : "+v"(qx));
+                qx = qx < (unsigned)a.Nq ? qx : (unsigned)a.Nq - 1u;
+                const uint2 qb = reinterpret_cast<const uint2 *>(m.qbound)[qx];
                 const float hab = __uint_as_float(qb.x), bbl = __uint_as_float(~qb.y);
                 below = active && dmax < bbl;
                 und = !low && !(below || dmin >= hab);
@@ -767,7 +804,16 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
                                 const float sc = sum / (float)L;
                                 const unsigned id = (unsigned)(a.id_base + mbase + moment_index(n, s, s + L - 1));
                                 const unsigned long long key = make_key(sc, id);
-                                if (key < thr) { col[(size_t)cnt * 64 + lane] = key; ++cnt; }
+                                if (key < thr) {
+                                    col[(size_t)cnt * 64 + lane] = key; ++cnt;
+                                    if (hon) {
+                                        const uint2 hr = m.hrange[qi];
+                                        const unsigned hlob = hr.x, hshift = hr.y - 1u;
+                                        const unsigned sbk = __float_as_uint(sc);
+                                        const unsigned bin = (sbk > hlob ? sbk - hlob : 0u) >> hshift;
+                                        atomicAdd(m.hist + (size_t)qi * MF_HBINS + (bin < MF_HBINS - 1 ? bin : MF_HBINS - 1), 1u);
+                                    }
+                                }
                             }
                         }
                     }

@@ -34,6 +34,7 @@ static std::atomic<int> g_opt_lstm_fast{1};        // 1: the table-start LSTM st
 static std::atomic<int> g_opt_vgg_halo{1};         // 1: the VGG stack on halo-padded activations where its shape allows (select-free convolution loader); 0: unpadded (cross-check)
 static std::atomic<int> g_opt_lstm_small4{1};      // 1: a single query of the model's shape takes the four-wave vector-chain step (weights streamed by three loader waves); 0: the one-wave step (cross-check)
 static std::atomic<int> g_opt_score_defer{8};      // MFMA pre-filter, whole-video early-out: skip the rank half of the moment triangle when at most this many lanes of a wave are left undecided by dmin / dmax (they are re-counted exactly); -1: off (cross-check)
+static std::atomic<int> g_opt_score_hist{1};       // MFMA pre-filter, top-k: 1 = the main launch's tasks tighten their threshold from a histogram of the candidates found so far; 0 = stage B's threshold throughout (cross-check)
 static std::atomic<int> g_opt_score_sort{1};       // MFMA pre-filter with rank keys: 1 = the pass runs on the batch sorted by difficulty (so that the whole-video early-out, a wave decision, sees homogeneous waves); 0 = caller's order (cross-check)
 static std::atomic<int> g_opt_lstm_tile{0};        // 0: by grid size, 1: 64-row tiles, 2: 128-row tiles (fused LSTM step)
 
@@ -41,7 +42,7 @@ struct Opt { const char *name; std::atomic<int> *v; };
 static const Opt g_opts[] = {
     {"gemm", &g_opt_gemm}, {"profile", &g_opt_profile}, {"score_fast", &g_opt_score_fast}, {"score_split", &g_opt_score_split},
     {"score_pre_b", &g_opt_score_pre_b}, {"score_smallq", &g_opt_score_smallq}, {"score_tasks", &g_opt_score_tasks}, {"lstm_skip0", &g_opt_lstm_skip0},
-    {"lstm_xcd", &g_opt_lstm_xcd}, {"gemm_small", &g_opt_gemm_small}, {"lstm_tile", &g_opt_lstm_tile}, {"lstm_small4", &g_opt_lstm_small4}, {"lstm_persist", &g_opt_lstm_persist}, {"lstm_persist_min", &g_opt_lstm_persist_min}, {"lstm_fast", &g_opt_lstm_fast}, {"lstm_persist_max", &g_opt_lstm_persist_max}, {"lstm_persist_fault", &g_opt_lstm_persist_fault}, {"vgg_fuse_pool", &g_opt_vgg_fuse_pool}, {"vgg_direct1", &g_opt_vgg_direct1}, {"vgg_halo", &g_opt_vgg_halo}, {"score_smallq_select", &g_opt_smallq_select}, {"gemm_pp", &g_opt_gemm_pp}, {"score_mfma_min", &g_opt_mfma_min}, {"lstm_small", &g_opt_lstm_small}, {"score_defer", &g_opt_score_defer}, {"score_sort", &g_opt_score_sort},
+    {"lstm_xcd", &g_opt_lstm_xcd}, {"gemm_small", &g_opt_gemm_small}, {"lstm_tile", &g_opt_lstm_tile}, {"lstm_small4", &g_opt_lstm_small4}, {"lstm_persist", &g_opt_lstm_persist}, {"lstm_persist_min", &g_opt_lstm_persist_min}, {"lstm_fast", &g_opt_lstm_fast}, {"lstm_persist_max", &g_opt_lstm_persist_max}, {"lstm_persist_fault", &g_opt_lstm_persist_fault}, {"vgg_fuse_pool", &g_opt_vgg_fuse_pool}, {"vgg_direct1", &g_opt_vgg_direct1}, {"vgg_halo", &g_opt_vgg_halo}, {"score_smallq_select", &g_opt_smallq_select}, {"gemm_pp", &g_opt_gemm_pp}, {"score_mfma_min", &g_opt_mfma_min}, {"lstm_small", &g_opt_lstm_small}, {"score_defer", &g_opt_score_defer}, {"score_sort", &g_opt_score_sort}, {"score_hist", &g_opt_score_hist},
 };
 
 struct ProfPair { int site; hipEvent_t a, b; };
@@ -125,6 +126,7 @@ int opt_gemm_pp() { return g_opt_gemm_pp; }
 int opt_mfma_min() { return g_opt_mfma_min; }
 int opt_score_defer() { return g_opt_score_defer; }
 int opt_score_sort() { return g_opt_score_sort; }
+int opt_score_hist() { return g_opt_score_hist; }
 
 struct FillArgs { unsigned *dst[4]; const unsigned *src[4]; unsigned long long words[4]; unsigned value[4]; unsigned long long start[5]; };
 __global__ __launch_bounds__(256) void fill_regions_kernel(FillArgs a)

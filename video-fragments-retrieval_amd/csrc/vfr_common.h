@@ -44,6 +44,7 @@ int opt_gemm_pp();
 int opt_mfma_min();
 int opt_score_defer();
 int opt_score_sort();
+int opt_score_hist();
 
 // ---- launch-site profiler (vfr_set_option("profile", 1)): HIP events recorded on the launch stream
 // around every instrumented launch; vfr_profile_read() turns them into per-site totals after a sync.
