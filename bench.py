@@ -81,7 +81,7 @@ def site_work(site, cfg):
     multiplying, and the first step's recurrent part (h_0 = 0) is skipped."""
     B, C, Nv, H, E, F, hid, D, n, Nq, T, vocab = (cfg[k] for k in ("Bq", "C", "Nv", "H", "E", "F", "hid", "D", "n", "Nq", "T", "vocab"))
     M = n * (n + 1) // 2
-    nb = min(640, Nv // 16) if Nv >= 256 else 0          # ladder stage B (score.hip: pre_b_videos)
+    nb = (min(640, Nv // 16) // 2 or min(640, Nv // 16)) if Nv >= 256 else 0   # ladder stage B (score.hip: pre_b_videos, halved beside the candidate histogram)
     rows = cfg["lstm_rows_per_step"]
     per_scoring = 2 * n * D + n + 2 * M
     world = cfg.get("world", 1)
