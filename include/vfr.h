@@ -17,10 +17,13 @@
  *     (thread-local).  No exception, exit or abort crosses the boundary.
  *   - no model state: weights are passed per call (no hidden model handle), so load_state_dict()/.to()
  *     on the Python side keep working.  Compute entry points are re-entrant: any number of host threads
- *     may call them concurrently (each on its own stream or sharing one).  The only process-wide state
- *     is the tuning options (vfr_set_option: atomic ints read once per call -- a knob for tests and
- *     sweeps, every setting gives the same bits) and the launch-site profiler (off by default; event
- *     pairs are owned by the calling scope, the totals are folded under a mutex)
+ *     may call them concurrently (each on its own stream or sharing one).  The process-wide state is:
+ *     the tuning options (vfr_set_option: PROCESS-GLOBAL atomic ints, read at the start of a call -- a
+ *     knob for tests and sweeps, every setting gives the same bits; do NOT change one while calls are in
+ *     flight on other threads: a call may then see the old value for one of its launches and the new
+ *     one for the next, which is harmless for the results but not a per-call setting), the fault word
+ *     registered with vfr_set_fault_word, and the launch-site profiler (off by default; event pairs
+ *     are owned by the calling scope, the totals are folded under a mutex)
  *   - numerics: every contraction is one k-ascending fp32 fma chain (what the fp32 MFMAs
  *     compute), so results are bit-identical to oracle/vfr_oracle.c on any input
  */
@@ -326,8 +329,12 @@ int vfr_math_f32(int op, const float *x, const float *y, float *out, int64_t n, 
  * array + selection tree), "vgg_fuse_pool" 1|0 (a 2x2 max-pool behind a VGG convolution runs in that convolution's epilogue |
  * its own kernel), "vgg_direct1" 1|0 (first VGG convolution as the direct kernel | the implicit-GEMM MFMA kernel), "vgg_halo" 1|0 (the VGG stack on
  * halo-padded activations where its shape allows: convolution loader without tap masks | unpadded), "lstm_fast" 1|0 (the
- * select-free instantiation of the table-start LSTM step where the launch qualifies | always the general form)
- * -- same bits either way.                                                                       */
+ * select-free instantiation of the table-start LSTM step where the launch qualifies | always the general form),
+ * "score_defer" N (vfr_score_topk_mfma, f32: whole-video early-out of the rank half of the moment triangle when at most N lanes of
+ * a wave are left undecided by the video's smallest / largest clip distance -- those are re-counted exactly; default 8, -1: off),
+ * "score_sort" 1|0|2 (the pre-filter pass with rank keys runs on the batch sorted by difficulty from 1024 queries x 2048 videos
+ * on | caller's order | sorted whatever the size), "score_hist" 1|0 (the main top-k launch tightens its threshold from a histogram
+ * of the candidates found so far | stage B's threshold throughout) -- same bits either way.  Options are process-global (see Conventions).        */
 int vfr_set_option(const char *name, int value);
 int vfr_get_option(const char *name);
 /* vfr_set_option("profile", 1): every instrumented launch is bracketed by two hipEvents recorded on

@@ -18,6 +18,10 @@ _vfr.set_option("score_mfma_min", 0)
 fell = 0
 bad = 0
 for it in range(ncfg):
+    if MODE == "mfma":       # the round-4 switches too: sorted pass whatever the size (2) or by size (1), early-out deferral, histogram threshold
+        _vfr.set_option("score_sort", int(rs.choice([1, 2, 2])))
+        _vfr.set_option("score_defer", int(rs.choice([-1, 0, 8, 8, 20])))
+        _vfr.set_option("score_hist", int(rs.choice([0, 1, 1])))
     shape = rs.choice(["n21", "n6", "ragged56", "ragged21"])
     nv = int(rs.choice([1, 3, 31, 33, 100, 257, 600, 1100, 3000]))
     nq = int(rs.choice([1, 5, 63, 64, 65, 200, 1000]))
