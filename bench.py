@@ -508,9 +508,23 @@ def extras(args, dev, model, seg, ctx, clip_off, tokens, make_shard, ranks_of, o
             tk = tokens[:nq].contiguous()
             own_s = np.asarray(ranks_of.own[:nq])
             sub = ranks_of.subset(nq)
-            dt_q, _ = _timed(lambda: sub(shard, engine.encode_queries(model, tk, dev, ops)), 5)
+            dt_q, out_e = _timed(lambda: sub(shard, engine.encode_queries(model, tk, dev, ops)), 5)
             small[str(nq)] = {"ms": dt_q * 1e3, "scorings_per_s": nq * Nv / dt_q}
-        ex["small_batches"] = {"what": "query encoder + labels + fused scoring of Nq queries against the resident clip bank", **small}
+            if nq <= 64:
+                # the same request replayed as a captured HIP graph (engine.GraphedRequest): no per-launch host work
+                try:
+                    own_all, times_all = synth.annotations(Nq, counts_all, seed=123)
+                    gr = engine.GraphedRequest(model, shard, nq, args.k, ops)
+                    gr.load(tk.cpu().numpy(), times_all[:nq], own_all[:nq])
+                    gr.replay(); torch.cuda.synchronize(); gr.check()
+                    dt_g, out_g = _timed(gr.replay, 20)
+                    small[str(nq)].update({"graph_replay_ms": dt_g * 1e3,
+                                           "graph_identical_to_eager": bool(all(torch.equal(a_, b_) for a_, b_ in zip(out_g, out_e)))})
+                    del gr
+                except Exception as e:                      # reported, never hidden; the eager figure above stands
+                    small[str(nq)]["graph_replay_error"] = f"{type(e).__name__}: {str(e)[:160]}"
+        ex["small_batches"] = {"what": "query encoder + labels + fused scoring of Nq queries against the resident clip bank (ms: launched from "
+                                       "Python call by call; graph_replay_ms: the same pass captured once as a HIP graph and replayed)", **small}
         # ---- the scorer with RETRIEVABLE ground truth: the bench batch's encoded queries land mid-distribution (random weights:
         # R@100 = 0, the pre-filter's worst case for rank keys); here each query is planted next to the clips of its first
         # annotated span in its own video (centroid + isotropic noise) so the best ground-truth moment sits in the near tail,

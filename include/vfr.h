@@ -216,6 +216,14 @@ int vfr_topk_merge_keys_strided(const int64_t *part_keys, int64_t slot_stride, i
 int vfr_gt_best_keys_f32(const float *own_scores, int64_t n_sel, int M, int score_stride, const uint8_t *labels, int R,
                          int label_stride, const int64_t *id_base, const int64_t *sel, int64_t Nq, int64_t *keys,
                          vfr_stream_t stream);
+/* The same, plus what a single-shard caller does with the keys next, in the same two launches (a serving request is a chain
+ * of short dependent launches: every one saved is ~10 us of its latency): rank_dist / rank_idx [R, Nq] (nullable, together) =
+ * the keys unpacked into the rank-key arguments of vfr_score_topk_* ((+inf, 0xffffffff) where there is none); count_zero
+ * [R, Nq] int64 (nullable) is zeroed (the count_lt argument those entry points ADD to); *missing (device int, nullable) = 1 iff
+ * some (threshold, selected query) has no positive moment, else 0 -- model/evaluate.py:77's IndexError condition.          */
+int vfr_gt_rank_keys_f32(const float *own_scores, int64_t n_sel, int M, int score_stride, const uint8_t *labels, int R,
+                         int label_stride, const int64_t *id_base, const int64_t *sel, int64_t Nq, int64_t *keys,
+                         float *rank_dist, int64_t *rank_idx, int64_t *count_zero, int *missing, vfr_stream_t stream);
 
 /* a11  ground-truth labels (model/evaluate.py:59-62 with utils.get_iou, model/utils.py:78-82; main.py:161 uses >=):
  * labels[r][q][m] = 1 iff >= 2 annotators of query q have IoU > thr[r] (strict != 0) or >= thr[r] with local moment m

@@ -653,6 +653,57 @@ def test_mfma_whole_video_early_out(vfr, oracle, max_n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nq", [1, 5, 40])
+def test_graphed_request_replays_the_eager_pass(vfr, nq):
+    """engine.GraphedRequest: the serving pass (query encoder + a11 labels + best-GT keys + fused top-k / rank counts) captured
+    once into a HIP graph and replayed for new requests loaded into its static buffers: rank counts, top-k ids and distances
+    == the eager `corpus_ranks` pass on the same request, bit for bit (the same C-ABI calls, replayed); a request without a
+    ground-truth-positive moment raises the reference's IndexError from `check()` (model/evaluate.py:77)."""
+    from vfr_amd import engine, models
+    F = 64
+    counts = synth.clip_counts(300, "didemo", seed=5)
+    counts[7] = 21
+    off = synth.clip_offsets(counts)
+    mom = np.concatenate([[0], np.cumsum(counts.astype(np.int64) * (counts + 1) // 2)])
+    seg, ctx = synth.video_features(counts, F, seed=5)
+    sd = synth.model_weights(F, vocab=90, seed=5)
+    model = models.CALModel(2 * F + 2, pretrained_emb=torch.from_numpy(sd["word_embedding.weight"]))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(DEV).eval()
+    ops = engine.HipOps()
+    with torch.no_grad():
+        emb = model.encode_clips(dev(seg), dev(ctx), dev(off.astype(np.int32)))
+    bank = vfr.VideoBank(emb, dev(off.astype(np.int32)), 0, max_clips=int(counts.max()), total_moments=int(mom[-1]), min_clips=int(counts.min()))
+    shard = engine.CorpusShard(bank, 0, len(counts), counts, mom, torch.device(DEV))
+    k = 20
+    gr = engine.GraphedRequest(model, shard, nq, k, ops)
+    for seed in (11, 12, 13):
+        tokens = synth.query_tokens(nq, vocab=90, seed=seed)
+        own, times = synth.annotations(nq, counts, seed=seed)
+        with torch.no_grad():
+            gr.load(tokens, times, own)
+            counts_g, d_g, i_g = gr.replay()
+            torch.cuda.synchronize()
+            gr.check()
+            got = (counts_g.clone(), d_g.clone(), i_g.clone())
+            Q = engine.encode_queries(model, dev(tokens), torch.device(DEV), ops)
+            labels = engine.gt_labels(times, counts[own], [0.5, 0.7], True, torch.device(DEV), ops)
+            want = engine.corpus_ranks(shard, Q, own, labels, ops, k=k)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2]) and torch.equal(got[1], want[1]), (nq, seed)
+    # a query whose annotators agree on nothing: no positive moment at IoU 0.7 -> the flag, read after the replay
+    tokens = synth.query_tokens(nq, vocab=90, seed=14)
+    own, times = synth.annotations(nq, counts, seed=14)
+    n0 = int(counts[own[0]])
+    times[0] = [[0, 0], [n0 - 1, n0 - 1], [0, n0 - 1], [n0 // 2, n0 // 2]]
+    with torch.no_grad():
+        gr.load(tokens, times, own)
+        gr.replay()
+        torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        gr.check()
+
+
+@pytest.mark.gpu
 def test_mfma_selfcheck_passes_and_can_fail(vfr):
     """What the pre-filter's margins assume about the matrix pipe -- one v_mfma_f32_16x16x4_f32 = four fp32 fmas, k ascending,
     denormals kept -- checked on THIS device against an explicit fmaf chain on adversarial rows (wide exponents, cancelling

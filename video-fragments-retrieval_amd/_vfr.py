@@ -57,6 +57,7 @@ SIGNATURES = {
     "vfr_topk_merge_keys": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "vfr_topk_merge_keys_strided": (_i32, [_vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "vfr_gt_best_keys_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "vfr_gt_rank_keys_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vfr_gt_labels_u8": (_i32, [_vp, _vp, _vp, _i64, _i32, ctypes.POINTER(ctypes.c_double), _i32, _i32, _i32, _vp, _vp]),
     "vfr_ranking_loss_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "vfr_ranking_loss_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _sz, _vp]),
@@ -523,6 +524,27 @@ def gt_best_keys(own_scores: torch.Tensor, labels: torch.Tensor, id_base: torch.
     _check(lib().vfr_gt_best_keys_f32(sc.data_ptr(), n_sel, min(sc.shape[1], Ml), sc.shape[1], lab.data_ptr(), R, Ml,
                                       base.data_ptr(), sel.data_ptr(), Nq, keys.data_ptr(), _stream()), "vfr_gt_best_keys_f32")
     return keys
+
+
+def gt_rank_keys(own_scores: torch.Tensor, labels: torch.Tensor, id_base: torch.Tensor, sel: torch.Tensor, Nq: int):
+    """``gt_best_keys`` plus, from the same two launches: the keys unpacked as (rank_dist f32 [R, Nq], rank_idx int64 [R, Nq]), a
+    zeroed count buffer int64 [R, Nq] and the device flag (int32 [1]) "some selected query has no positive moment"."""
+    sc = _dev(own_scores, torch.float32, "own_scores")
+    lab = labels.view(torch.uint8) if labels.dtype == torch.bool else labels
+    lab = _dev(lab, torch.uint8, "labels")
+    base, sel = _dev(id_base, torch.int64, "id_base"), _dev(sel, torch.int64, "sel")
+    R, n_sel, Ml = lab.shape
+    if sc.shape[0] != n_sel or base.numel() != n_sel or sel.numel() != n_sel:
+        raise RuntimeError("gt_rank_keys: inconsistent shapes")
+    keys = torch.empty((R, Nq), dtype=torch.int64, device=sc.device)
+    rd = torch.empty((R, Nq), dtype=torch.float32, device=sc.device)
+    ri = torch.empty((R, Nq), dtype=torch.int64, device=sc.device)
+    cnt = torch.empty((R, Nq), dtype=torch.int64, device=sc.device)
+    missing = torch.empty((1,), dtype=torch.int32, device=sc.device)
+    _check(lib().vfr_gt_rank_keys_f32(sc.data_ptr(), n_sel, min(sc.shape[1], Ml), sc.shape[1], lab.data_ptr(), R, Ml, base.data_ptr(),
+                                      sel.data_ptr(), Nq, keys.data_ptr(), rd.data_ptr(), ri.data_ptr(), cnt.data_ptr(), missing.data_ptr(),
+                                      _stream()), "vfr_gt_rank_keys_f32")
+    return keys, rd, ri, cnt, missing
 
 
 def gt_labels(times: torch.Tensor, nannot: torch.Tensor, n_own: torch.Tensor, thresholds, strict: bool, Mmax: int):

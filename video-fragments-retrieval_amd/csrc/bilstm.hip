@@ -18,6 +18,19 @@
 
 namespace vfr {
 
+// plain gather (no learnable length): one thread per ELEMENT (a thread per row copied its E floats one after the other: 10 us
+// for the 20 rows of a single-query request)
+__global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t *__restrict__ tokens, int64_t rows, int vocab,
+                                                           const float *__restrict__ emb, int E, float *__restrict__ X)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * E) return;
+    const int64_t r = i / E;
+    const int k = (int)(i - r * E);
+    int64_t tok = tokens ? tokens[r] : r;
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    X[i] = emb[tok * E + k];
+}
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t *__restrict__ tokens, int64_t rows, int vocab,
                                                     const float *__restrict__ emb, const float *__restrict__ len_tab,
                                                     int E, float *__restrict__ X)
@@ -36,6 +49,15 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t *__restrict__ 
     for (int k = 0; k < E; ++k) acc = __builtin_fmaf(e[k], e[k], acc);
     const float nrm = __builtin_sqrtf(acc) + 1e-5f, len = len_tab[tok];
     for (int k = 0; k < E; ++k) x[k] = (e[k] / nrm) * len;
+}
+
+static void launch_embed(const int64_t *tokens, int64_t rows, int vocab, const float *emb, const float *len_tab, int E, float *X,
+                         hipStream_t st)
+{
+    if (!len_tab)
+        hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)cdiv(rows * E, 256)), dim3(256), 0, st, tokens, rows, vocab, emb, E, X);
+    else
+        hipLaunchKernelGGL(embed_kernel, dim3((unsigned)cdiv(rows, 256)), dim3(256), 0, st, tokens, rows, vocab, emb, len_tab, E, X);
 }
 
 // gates [2][B,4H] (chains without bias) -> + (b_ih + b_hh) -> c [2][B,H] (in place), h into hcat [B,2H] at column d*H
@@ -1032,8 +1054,7 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
         if (int rc = vfr::fill_region(w.hg, 0u, gbytes, st)) return rc;
         {
         vfr::ProfScope prof(vfr::SITE_EMBED, st);
-        hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(B * T, 256)), dim3(256), 0, st, tokens, B * T, vocab, emb, len_tab,
-                           E, w.X);
+        vfr::launch_embed(tokens, B * T, vocab, emb, len_tab, E, w.X, st);
         }
         VFR_CHECK_LAUNCH("embed_kernel");
         const dim3 grid(2 * (unsigned)vfr::cdiv(H, 8));
@@ -1064,8 +1085,7 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
         }
         {
         vfr::ProfScope prof(vfr::SITE_EMBED, st);
-        hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(B * T, 256)), dim3(256), 0, st, tokens, B * T, vocab, emb, len_tab,
-                           E, w.X);
+        vfr::launch_embed(tokens, B * T, vocab, emb, len_tab, E, w.X, st);
         }
         VFR_CHECK_LAUNCH("embed_kernel");
         // one or two queries at a shape whose 32-column weight slices fit a CU's LDS: the whole sequence in one launch
@@ -1145,11 +1165,9 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
     {
     vfr::ProfScope prof(vfr::SITE_EMBED, st);
     if (table)          // one embedded row per VOCABULARY entry (the steps start their chains from the projection table)
-        hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(vocab, 256)), dim3(256), 0, st, (const int64_t *)nullptr,
-                           (int64_t)vocab, vocab, emb, len_tab, E, w.xv);
+        vfr::launch_embed(nullptr, (int64_t)vocab, vocab, emb, len_tab, E, w.xv, st);
     else
-        hipLaunchKernelGGL(vfr::embed_kernel, dim3((unsigned)vfr::cdiv(R * T, 256)), dim3(256), 0, st, w.tok_ext, R * T, vocab,
-                           emb, len_tab, E, w.X);
+        vfr::launch_embed(w.tok_ext, R * T, vocab, emb, len_tab, E, w.X, st);
     hipLaunchKernelGGL(vfr::query_length_kernel, dim3((unsigned)vfr::cdiv(B, 256)), dim3(256), 0, st, tokens, B, T, w.len);
     hipLaunchKernelGGL(vfr::length_hist_kernel, dim3((unsigned)vfr::cdiv(B, vfr::SORT_BLOCK)), dim3(vfr::SORT_BLOCK), 0, st,
                        w.len, B, T, w.hist);

@@ -1017,11 +1017,24 @@ __global__ __launch_bounds__(256) void gt_fill_keys_kernel(int64_t n, int64_t *_
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) keys[i] = (int64_t)KEY_EMPTY;
 }
+// the same initialisation with the unpacked forms of vfr_gt_rank_keys_f32: distance +inf, id 0xffffffff, counts 0, flag 0
+__global__ __launch_bounds__(256) void gt_fill_rank_kernel(int64_t n, int64_t *__restrict__ keys, float *__restrict__ rank_dist,
+                                                           int64_t *__restrict__ rank_idx, int64_t *__restrict__ count0,
+                                                           int *__restrict__ missing)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && missing) *missing = 0;
+    if (i >= n) return;
+    keys[i] = (int64_t)KEY_EMPTY;
+    if (rank_dist) { rank_dist[i] = __builtin_inff(); rank_idx[i] = 0xFFFFFFFFll; }
+    if (count0) count0[i] = 0;
+}
 __global__ __launch_bounds__(256) void gt_best_keys_kernel(const float *__restrict__ sc, int64_t n_sel, int M,
                                                            int score_stride, const uint8_t *__restrict__ labels, int R,
                                                            int label_stride, const int64_t *__restrict__ id_base,
                                                            const int64_t *__restrict__ sel, int64_t Nq,
-                                                           int64_t *__restrict__ keys)
+                                                           int64_t *__restrict__ keys, float *__restrict__ rank_dist = nullptr,
+                                                           int64_t *__restrict__ rank_idx = nullptr, int *__restrict__ missing = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1040,7 +1053,15 @@ __global__ __launch_bounds__(256) void gt_best_keys_kernel(const float *__restri
             const unsigned long long o = __shfl_xor(best, d, 64);
             best = o < best ? o : best;
         }
-        if (lane == 0) keys[(int64_t)r * Nq + q] = (int64_t)(best >= KEY_EMPTY ? KEY_EMPTY : best);
+        if (lane == 0) {
+            const unsigned long long kq = best >= KEY_EMPTY ? KEY_EMPTY : best;
+            keys[(int64_t)r * Nq + q] = (int64_t)kq;
+            if (rank_dist) {
+                rank_dist[(int64_t)r * Nq + q] = __uint_as_float((unsigned)(kq >> 32));
+                rank_idx[(int64_t)r * Nq + q] = (int64_t)(kq & 0xffffffffull);
+            }
+            if (missing && kq == KEY_EMPTY) atomicOr(missing, 1);
+        }
     }
 }
 
@@ -2223,6 +2244,26 @@ int vfr_gt_best_keys_f32(const float *own_scores, int64_t n_sel, int M, int scor
     if (n_sel == 0) return VFR_OK;
     hipLaunchKernelGGL(vfr::gt_best_keys_kernel, dim3((unsigned)vfr::cdiv(n_sel, 4)), dim3(256), 0, vfr::as_stream(stream),
                        own_scores, n_sel, M, score_stride, labels, R, label_stride, id_base, sel, Nq, keys);
+    VFR_CHECK_LAUNCH("gt_best_keys_kernel");
+    return VFR_OK;
+}
+
+int vfr_gt_rank_keys_f32(const float *own_scores, int64_t n_sel, int M, int score_stride, const uint8_t *labels, int R,
+                         int label_stride, const int64_t *id_base, const int64_t *sel, int64_t Nq, int64_t *keys,
+                         float *rank_dist, int64_t *rank_idx, int64_t *count_zero, int *missing, vfr_stream_t stream)
+{
+    VFR_REQUIRE(keys && R > 0 && Nq >= 0 && n_sel >= 0 && M >= 0 && score_stride >= M && label_stride >= M, VFR_EINVAL,
+                "vfr_gt_rank_keys_f32: bad argument");
+    VFR_REQUIRE(n_sel == 0 || (own_scores && labels && id_base && sel), VFR_EINVAL, "vfr_gt_rank_keys_f32: null input");
+    VFR_REQUIRE((rank_dist == nullptr) == (rank_idx == nullptr), VFR_EINVAL, "vfr_gt_rank_keys_f32: rank_dist and rank_idx go together");
+    if (Nq == 0) return VFR_OK;
+    vfr::ProfScope prof(vfr::SITE_EXCHANGE, vfr::as_stream(stream));
+    hipLaunchKernelGGL(vfr::gt_fill_rank_kernel, dim3((unsigned)vfr::cdiv((int64_t)R * Nq, 256)), dim3(256), 0, vfr::as_stream(stream),
+                       (int64_t)R * Nq, keys, rank_dist, rank_idx, count_zero, missing);
+    VFR_CHECK_LAUNCH("gt_fill_rank_kernel");
+    if (n_sel == 0) return VFR_OK;
+    hipLaunchKernelGGL(vfr::gt_best_keys_kernel, dim3((unsigned)vfr::cdiv(n_sel, 4)), dim3(256), 0, vfr::as_stream(stream),
+                       own_scores, n_sel, M, score_stride, labels, R, label_stride, id_base, sel, Nq, keys, rank_dist, rank_idx, missing);
     VFR_CHECK_LAUNCH("gt_best_keys_kernel");
     return VFR_OK;
 }
