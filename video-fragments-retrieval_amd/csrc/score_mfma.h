@@ -69,7 +69,7 @@ struct MfmaArgs {
                                              //   [1] ~bits of BBL: dmax <  BBL => every moment of the video is counted, for both keys
     unsigned *hist;                          // [Nq][MF_HBINS] top-k threshold histogram (nullable; zeroed per call): counts of candidate keys by score
     uint2 *hrange;                           // [Nq] {score bits of bin 0's lower edge, 1 + log2(bin width in bits)}; .y == 0: histogram not in use for the query
-    const int *diff, *perm;                  // sorted pass (nullable): diff[perm[p]] = difficulty (0 .. SORT_SAMPLE) of the query at sorted position p
+    const int *diff, *perm;                  // sorted pass (nullable): diff[perm[p]] >> 24 = difficulty (0 .. SORT_SAMPLE) of the query at sorted position p
     int defer_max;                           // whole-video early-out: the rank half of the triangle is skipped when at most this many
                                              // lanes of the wave are left undecided by HAB / BBL; those lanes are marked ambiguous
                                              // (re-counted exactly by score_pairs_video_kernel).  < 0: early-out off
@@ -298,12 +298,13 @@ __global__ __launch_bounds__(256) void mfma_prep_tab_kernel(int64_t Nq, int NR, 
 // Query order.  The whole-video early-out of score_mfma_kernel is a WAVE decision (64 queries), and query batches are
 // mixtures: with rank keys in the near tail half the queries leave (almost) no video undecided while a quarter leave most
 // of them -- one such query per wave and the wave runs every triangle.  So the pass runs on a permutation of the batch:
-// queries sorted by DIFFICULTY = how many of 64 sample videos (evenly spaced through the bank) the query's smaller rank key
-// leaves undecided (smallest clip distance below the key, largest not).  A heuristic on plain arithmetic (no margins): it
+// queries sorted by DIFFICULTY = how many of SORT_SAMPLE sample videos (evenly spaced through the bank) the query's smaller rank key
+// leaves undecided (smallest clip distance below the key, largest not), then the key distance itself.  A heuristic on plain arithmetic (no margins): it
 // only chooses which queries share a wave; every result is computed as before and scattered back to the caller's order.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int SORT_MAX_QUERIES = 12288;      // (the rank computation keeps every key in LDS: 48 KB)
-constexpr int SORT_SAMPLE = 64;              // sample videos per query
+constexpr int SORT_SAMPLE = 8;               // sample videos per query (64 were measured first: the sample pass then cost 70 us, as much as the
+                                             // sort saves on a corpus whose every query is hard; 8 videos + the key distance order nearly as well)
 // wave-task (query group, sample video): lane = query (its row in registers), the video's clip rows are wave-uniform (scalar
 // loads); a lane for which the video is undecided adds one to its query's count
 __global__ __launch_bounds__(64) void mfma_difficulty_kernel(const float *__restrict__ Q, int64_t Nq, const float *__restrict__ V,
@@ -336,7 +337,10 @@ __global__ __launch_bounds__(64) void mfma_difficulty_kernel(const float *__rest
         dmax2 = acc > dmax2 ? acc : dmax2;
     }
     const float x2 = x * x;
-    if (active && c1 > c0 && dmin2 < x2 * 1.0002f && !(dmax2 < x2 * 0.9998f)) atomicAdd(diff + q, 1);
+    // sort key: (undecided sample videos) << 24 | the top 24 bits of the key distance -- among queries that leave the same
+    // number of sample videos undecided the one with the smaller key is the easier (its key sits deeper in the tail)
+    if (active && c1 > c0 && dmin2 < x2 * 1.0002f && !(dmax2 < x2 * 0.9998f)) atomicAdd(diff + q, 1 << 24);
+    if (active && sv == 0) atomicAdd(diff + q, (int)((__float_as_uint(x < 0.0f ? 0.0f : x) >> 7) & 0xFFFFFFu));
 }
 // perm[rank] = q with rank = #{j : diff[j] < diff[q]} + #{j < q : diff[j] == diff[q]} (a stable sort, deterministic); 16 lanes
 // share a query's scan over all keys (LDS)
@@ -522,8 +526,8 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
     if (NR > 0 && defer_max >= 0 && m.diff) {
         // a wave whose every query left (nearly) all sample videos undecided will not see a decidable video either: it runs without
         // the test (mid-distribution keys: the whole batch)
-        const int dq = active ? m.diff[m.perm[qi]] : 64;
-        if (__ballot(dq < 63) == 0ull) defer_max = -1;
+        const int dq = active ? (m.diff[m.perm[qi]] >> 24) : SORT_SAMPLE;
+        if (__ballot(dq < SORT_SAMPLE) == 0ull) defer_max = -1;
     }
 
 
