@@ -164,7 +164,8 @@ int vfr_score_topk_f32(const float *Q, int64_t Nq, const float *V, const int32_t
  * and compares {hash, total_clips, Nv, D, eps, bf16 copy present} with the signature stored next to the products; on any
  * difference the products are recomputed inside the same call (the pre-pass kernels are always enqueued and return at once
  * when the signature matches -- no host decision, no synchronisation).  A bank rewritten through a raw pointer therefore
- * costs a recomputation, never a wrong result.  NOT checked: that the product region of `workspace` itself is intact --
+ * costs a recomputation, never a wrong result.  (The hash is a position-weighted 64-bit sum: it catches accidental rewrites,
+ * it is not collision-resistant against an adversary who chooses the bank.)  NOT checked: that the product region of `workspace` itself is intact --
  * that part stays the caller's statement (do not set the flag for a workspace other code has used in between).
  * vfr_score_topk_mfma_prefilter: 1 if a call with these shapes runs the pre-filter (and therefore leaves the bank-side
  * products in its workspace), 0 if it is handed to the exact kernels.                            */

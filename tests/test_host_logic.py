@@ -444,6 +444,17 @@ def test_extract_dataset_resume_and_missed_bookkeeping(tmp_path, monkeypatch):
         features.extract_dataset(info, decoder, ft, None, model_type="resnet50", missed_path=missed_file)
 
 
+def test_resnet_packed_is_a_plain_pair_with_a_fold_cache():
+    """`_vfr.resnet_pack` returns a tuple subclass: callers (features.extract_video, the tests) unpack it as (convs, bns); the folded
+    weights `resnet_pool` computes once per (blocks, width, eps, device) live in its `.folded` dict."""
+    from vfr_amd import _vfr
+    p = _vfr.ResnetPacked(([1, 2], [3, 4]))
+    convs, bns = p
+    assert convs == [1, 2] and bns == [3, 4] and isinstance(p, tuple) and len(p) == 2 and p.folded == {}
+    p.folded["k"] = 1
+    assert _vfr.ResnetPacked(([], [])).folded == {}            # per instance, not shared
+
+
 def test_resnet_plan_and_frame_selection_host_side(oracle):
     """f4 host logic: the product's convolution order for vfr_resnet_pool_f32 == the oracle's execution plan (names, count =
     1 + sum(3 n + 1)); features.select_frames gathers on the host, passes a pre-selected clip through (fps <= 0) and keeps dtype."""

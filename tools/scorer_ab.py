@@ -7,7 +7,7 @@ Builds the bench corpus's embeddings (seeded features through the clip / query e
 scoring pass -- labels + own-video scores + fused top-100 + rank counts at IoU 0.5 / 0.7, what `engine.corpus_ranks` runs --
 in two regimes: `bench` (the encoded queries: rank keys mid-distribution) and `planted` (bench.py's realistic_gt: every query
 next to the clips of its first annotated span: rank keys in the near tail).  Every combination of the option values given on
-the command line is run; per combination the profiler sites of the scorer are printed, and the outputs (rank counts, top-k ids
+the command line is run (`--zip`: the i-th values of every option together); per combination the profiler sites of the scorer are printed, and the outputs (rank counts, top-k ids
 and distances) must be IDENTICAL across all combinations (the first is the reference) -- a mismatch is an error."""
 import itertools
 import sys
@@ -29,12 +29,14 @@ def main():
     args = sys.argv[1:]
     Nv, Nq, clips, k, F = 10000, 5000, "21", 100, 4096
     sweeps = []
+    zipped = False                          # --zip: the i-th values of every option together (e.g. all switches off, then all on)
     i = 0
     while i < len(args):
         if args[i] == "--videos": Nv = int(args[i + 1]); i += 2
         elif args[i] == "--queries": Nq = int(args[i + 1]); i += 2
         elif args[i] == "--clips": clips = args[i + 1]; i += 2
         elif args[i] == "--feat-dim": F = int(args[i + 1]); i += 2
+        elif args[i] == "--zip": zipped = True; i += 1
         else:
             name, vals = args[i].split("=")
             sweeps.append((name, [int(v) for v in vals.split(",")]))
@@ -88,7 +90,7 @@ def main():
     Qp = (centre + 0.5 * d_typ / 10.0 * torch.randn(centre.shape, device=dev, generator=g)).contiguous()
 
     names = [n for n, _ in sweeps]
-    combos = list(itertools.product(*[v for _, v in sweeps])) or [()]
+    combos = (list(zip(*[v for _, v in sweeps])) if zipped else list(itertools.product(*[v for _, v in sweeps]))) or [()]
     print(f"# scorer_ab: {Nv} videos x {clips} clips, {Nq} queries, k = {k}; options {names or '(defaults)'}")
     for regime, Qx in (("bench", Q), ("planted", Qp)):
         ref = None
