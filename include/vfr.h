@@ -341,7 +341,7 @@ int vfr_math_f32(int op, const float *x, const float *y, float *out, int64_t n, 
  * select-free instantiation of the table-start LSTM step where the launch qualifies | always the general form),
  * "score_defer" N (vfr_score_topk_mfma, f32: whole-video early-out of the rank half of the moment triangle when at most N lanes of
  * a wave are left undecided by the video's smallest / largest clip distance -- those are re-counted exactly; default 8, -1: off),
- * "score_sort" 1|0|2 (the pre-filter pass with rank keys runs on the batch sorted by difficulty from 1024 queries x 2048 videos
+ * "score_sort" 1|0|2 (the pre-filter pass with rank keys runs on the batch sorted by difficulty from 1024 queries x 4096 videos
  * on | caller's order | sorted whatever the size), "score_hist" 1|0 (the main top-k launch tightens its threshold from a histogram
  * of the candidates found so far | stage B's threshold throughout) -- same bits either way.  Options are process-global (see Conventions).        */
 int vfr_set_option(const char *name, int value);

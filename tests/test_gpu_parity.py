@@ -604,7 +604,7 @@ def test_mfma_whole_video_early_out(vfr, oracle, max_n):
     total = dense.shape[1]
     order = torch.argsort(dense, dim=1, stable=True)
     old = vfr.get_option("score_defer")
-    vfr.set_option("score_sort", 2)                # (2: sort whatever the bank size -- the default waits for 2048 videos x 1024 queries)
+    vfr.set_option("score_sort", 2)                # (2: sort whatever the bank size -- the default waits for 4096 videos x 1024 queries)
     try:
         for pos in ((3, 40), (total // 2, 11), (total - 1, total - 7)):
             rd = torch.stack([dense.gather(1, order[:, p:p + 1]).squeeze(1) for p in pos]).contiguous()

@@ -1343,7 +1343,9 @@ static int run_pass(ScoreArgs a, const TopkWs &w, bool seeded, float *out_dist, 
         int nb = (fast && Nv >= (seeded ? 4096 : 256)) ? pre_b_videos(Nv) : 0;
         // (with the candidate histogram tightening the main launch's threshold as it goes, stage B need not be as long: half --
         // Nv / 32, at most 320 videos -- measured 1-2 % better at 10 000 videos, 21 and 6 clips: profiles/r4m_scorer_ab_pre_b.txt)
-        if (nb > 0 && a.mf_host && a.mf_host->hist && opt_score_pre_b() <= 0) nb = nb / 2 > 0 ? nb / 2 : nb;
+        // (not behind a caller's seed: there stage B is what turns the seed -- the k-th key of a 256-video sample -- into a list, and
+        // half of it starts the main launch looser than no histogram at all: tools/rank_sim.py 2, fused 2.49 -> 2.58 ms)
+        if (nb > 0 && !seeded && a.mf_host && a.mf_host->hist && opt_score_pre_b() <= 0) nb = nb / 2 > 0 ? nb / 2 : nb;
         if (k > 0 && !fast && !seeded && Nv <= 512) {
             // generic shapes, small banks: ~10 videos per task for the cooperative-compaction kernel
             const int c = Nv / 10 < 1 ? 1 : Nv / 10;
@@ -2006,9 +2008,14 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
     const int kp = k > 0 ? k + vfr::MF_EXTRA : 0;
     vfr::MfmaWs mw = vfr::carve_mfma(workspace, Nq, Nv, total_clips, k);
     vfr::TopkWs w = vfr::carve_topk(mw.topk, Nq, Nv, kp);
-    const bool sorted_plan = num_rank > 0 && vfr::opt_score_sort() && Nq >= (vfr::opt_score_sort() > 1 ? 128 : 1024) && Nq <= vfr::SORT_MAX_QUERIES &&
-                             (Nv >= 2048 || vfr::opt_score_sort() > 1) &&
-                             Nv >= 64 && D == vfr::FAST_D && ((((uintptr_t)V) | ((uintptr_t)Q)) & 15) == 0;
+    // the difficulty sample (8 videos per query: ~10 us) runs for every pass with rank keys -- a wave whose queries are all hard
+    // switches the early-out test off (the test costs ~6 % of the fused launch where it never fires) --; the SORT on top of it
+    // (rank, gather, scatter: ~0.06 ms) from 1024 queries x 4096 videos on (measured with tools/rank_sim.py: worth it at a rank's
+    // 5 000 videos, not at 2 500)
+    const bool diff_plan = num_rank > 0 && vfr::opt_score_defer() >= 0 && vfr::opt_score_sort() && Nv >= 64 && D == vfr::FAST_D &&
+                           ((((uintptr_t)V) | ((uintptr_t)Q)) & 15) == 0;
+    const bool sorted_plan = diff_plan && Nq >= (vfr::opt_score_sort() > 1 ? 128 : 1024) && Nq <= vfr::SORT_MAX_QUERIES &&
+                             (Nv >= 4096 || vfr::opt_score_sort() > 1);
     {
         // one launch: the zeroed region, the +inf thresholds of an unseeded top-k pass, the sorted pass's count buffer
         const vfr::FillJob jobs[3] = {{mw.zero_base, nullptr, mw.zero_bytes, 0u},
@@ -2022,10 +2029,14 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
     const bool sorted = sorted_plan;
     float *const out_dist_user = out_dist;
     int64_t *const out_idx_user = out_idx, *const count_lt_user = count_lt;
-    if (sorted) {
+    if (diff_plan) {
         vfr::ProfScope prof(vfr::SITE_SCORE_PREP, st);
         hipLaunchKernelGGL(vfr::mfma_difficulty_kernel, dim3((unsigned)(vfr::cdiv(Nq, 64) * vfr::SORT_SAMPLE)), dim3(64), 0, st, Q, Nq, V,
                            clip_offsets, Nv, num_rank, rank_dist, mw.diff);
+        VFR_CHECK_LAUNCH("mfma_difficulty_kernel");
+    }
+    if (sorted) {
+        vfr::ProfScope prof(vfr::SITE_SCORE_PREP, st);
         hipLaunchKernelGGL(vfr::mfma_sort_perm_kernel, dim3((unsigned)vfr::cdiv(Nq, 16)), dim3(256), 0, st, mw.diff, (int)Nq, mw.perm);
         hipLaunchKernelGGL(vfr::mfma_gather_queries_kernel, dim3((unsigned)vfr::cdiv(Nq * vfr::FAST_D, 256)), dim3(256), 0, st, mw.perm, Nq, Q,
                            num_rank, rank_dist, rank_idx, thr_seed, mw.Qs, mw.rds, mw.ris, mw.seeds);
@@ -2047,7 +2058,7 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
     m.va = mw.va; m.qmeta = mw.qmeta; m.tab = mw.tab; m.cnt_ws = mw.cnt_ws; m.amb = mw.amb; m.pairs_total = mw.pairs_total; m.wmax = mw.wmax;
     m.fallback = mw.fallback; m.vb = bf16 ? mw.vb : nullptr; m.rv = mw.rv; m.vc = mw.vc; m.qc = mw.qc;
     m.qbound = mw.qbound; m.defer_max = vfr::opt_score_defer();
-    m.diff = sorted ? mw.diff : nullptr; m.perm = sorted ? mw.perm : nullptr;
+    m.diff = diff_plan ? mw.diff : nullptr; m.perm = sorted ? mw.perm : nullptr;
     m.hist = (k > 0 && vfr::opt_score_hist()) ? mw.hist : nullptr; m.hrange = mw.hrange;
     {
         vfr::ProfScope prof(vfr::SITE_SCORE_PREP, st);

@@ -69,7 +69,7 @@ struct MfmaArgs {
                                              //   [1] ~bits of BBL: dmax <  BBL => every moment of the video is counted, for both keys
     unsigned *hist;                          // [Nq][MF_HBINS] top-k threshold histogram (nullable; zeroed per call): counts of candidate keys by score
     uint2 *hrange;                           // [Nq] {score bits of bin 0's lower edge, 1 + log2(bin width in bits)}; .y == 0: histogram not in use for the query
-    const int *diff, *perm;                  // sorted pass (nullable): diff[perm[p]] >> 24 = difficulty (0 .. SORT_SAMPLE) of the query at sorted position p
+    const int *diff, *perm;                  // (nullable) diff[q] >> 24 = difficulty (0 .. SORT_SAMPLE) of query q; perm[p] = the query at sorted position p (sorted pass)
     int defer_max;                           // whole-video early-out: the rank half of the triangle is skipped when at most this many
                                              // lanes of the wave are left undecided by HAB / BBL; those lanes are marked ambiguous
                                              // (re-counted exactly by score_pairs_video_kernel).  < 0: early-out off
@@ -526,7 +526,7 @@ void score_mfma_kernel(const float *__restrict__ Qp, const float *__restrict__ V
     if (NR > 0 && defer_max >= 0 && m.diff) {
         // a wave whose every query left (nearly) all sample videos undecided will not see a decidable video either: it runs without
         // the test (mid-distribution keys: the whole batch)
-        const int dq = active ? (m.diff[m.perm[qi]] >> 24) : SORT_SAMPLE;
+        const int dq = active ? (m.diff[m.perm ? m.perm[qi] : qi] >> 24) : SORT_SAMPLE;
         if (__ballot(dq < SORT_SAMPLE) == 0ull) defer_max = -1;
     }
 
