@@ -339,6 +339,9 @@ int vfr_math_f32(int op, const float *x, const float *y, float *out, int64_t n, 
  * its own kernel), "vgg_direct1" 1|0 (first VGG convolution as the direct kernel | the implicit-GEMM MFMA kernel), "vgg_halo" 1|0 (the VGG stack on
  * halo-padded activations where its shape allows: convolution loader without tap masks | unpadded), "lstm_fast" 1|0 (the
  * select-free instantiation of the table-start LSTM step where the launch qualifies | always the general form),
+ * "lstm_multi" 0|1 (EXPERIMENT, default 0: one launch per LSTM step | all T steps of both directions in one launch -- ordered task
+ * lists per XCD group, completion counters, agent-scope state traffic; with "lstm_tile" 2: 128-row tiles; a give-up is repaired by a
+ * rescue kernel and reported through the fault word like the sequence kernels'),
  * "score_defer" N (vfr_score_topk_mfma, f32: whole-video early-out of the rank half of the moment triangle when at most N lanes of
  * a wave are left undecided by the video's smallest / largest clip distance -- those are re-counted exactly; default 8, -1: off),
  * "score_sort" 1|0|2 (the pre-filter pass with rank keys runs on the batch sorted by difficulty from 1024 queries x 4096 videos

@@ -921,6 +921,71 @@ def test_bilstm_select_free_step_agrees(vfr, oracle):
 
 
 @pytest.mark.gpu
+def test_bilstm_multi_step_launch_agrees(vfr, oracle):
+    """EXPERIMENT `lstm_multi` (off by default): all T steps of both directions in ONE launch (`lstm_steps_mfma_kernel`: one
+    ordered task list per XCD group, completion counters per row tile, three rotating state buffers, the recurrent state moved
+    with agent-scope accesses) -- the same bits as one launch per step and as the oracle: 32-, 64- and 128-row tiles, H = 96
+    (three column tiles: five of the eight groups have nothing to do), a short sequence, an all-pad query."""
+    for H, B, T, tile in ((1000, 300, 20, 0), (1000, 900, 20, 0), (1000, 900, 20, 2), (96, 130, 20, 0), (1000, 200, 5, 0)):
+        sd = synth.model_weights(4096, seed=23, hidden=H)
+        tokens = synth.query_tokens(B, seed=23)[:, :T].copy()
+        tokens[3, :] = 0
+        args = (dev(tokens), dev(sd["word_embedding.weight"]), {k: dev(v) for k, v in lstm_of(sd).items()},
+                dev(sd["lang_fc.weight"]), dev(sd["lang_fc.bias"]))
+        per_step = vfr.bilstm_final(*args)
+        try:
+            vfr.set_option("lstm_multi", 1)
+            vfr.set_option("lstm_tile", tile)
+            one = vfr.bilstm_final(*args)
+            torch.cuda.synchronize()
+        finally:
+            vfr.set_option("lstm_multi", 0)
+            vfr.set_option("lstm_tile", 0)
+        assert vfr.poll_faults() == 0
+        assert torch.equal(one.view(torch.int32), per_step.view(torch.int32)), (H, B, T, tile)
+        # rows are encoded independently of each other: the oracle on a slice of the batch (its C loop is slow) must match that slice
+        rows = np.r_[0:24, B - 16:B]
+        want = oracle.bilstm_final(tokens[rows], sd["word_embedding.weight"], lstm_of(sd), sd["lang_fc.weight"], sd["lang_fc.bias"])
+        assert same(one[torch.from_numpy(rows).to(one.device)], want), (H, B, T, tile)
+
+
+@pytest.mark.gpu
+def test_multi_step_launch_give_up_is_repaired_and_reported(vfr, oracle):
+    """The multi-step launch waits on completion counters.  Test hook `lstm_persist_fault`: one task never signals; its
+    dependents must give up (bounded waits, no hang), every workgroup leaves, and the rescue kernel behind the launch
+    re-encodes every row: the call returns the RIGHT embeddings and the event reaches the host through the fault word."""
+    import time
+    import warnings
+    sd = synth.model_weights(4096, seed=29)
+    tokens = synth.query_tokens(100, seed=29)
+    args = (dev(tokens), dev(sd["word_embedding.weight"]), {k: dev(v) for k, v in lstm_of(sd).items()},
+            dev(sd["lang_fc.weight"]), dev(sd["lang_fc.bias"]))
+    good = vfr.bilstm_final(*args)
+    torch.cuda.synchronize()
+    assert vfr.poll_faults() == 0
+    try:
+        vfr.set_option("lstm_multi", 1)
+        vfr.set_option("lstm_persist_fault", 5)
+        t0 = time.perf_counter()
+        repaired = vfr.bilstm_final(*args)
+        torch.cuda.synchronize()
+        took = time.perf_counter() - t0
+    finally:
+        vfr.set_option("lstm_persist_fault", -1)
+        vfr.set_option("lstm_multi", 0)
+    assert took < 20.0
+    assert not bool(torch.isnan(repaired).any())
+    assert torch.equal(repaired.view(torch.int32), good.view(torch.int32))
+    want = oracle.bilstm_final(tokens, sd["word_embedding.weight"], lstm_of(sd), sd["lang_fc.weight"], sd["lang_fc.bias"])
+    assert same(repaired, want)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        bits = vfr.poll_faults()
+    assert bits & vfr.FAULT_SEQ_RESCUED and any("re-encoded" in str(w.message) for w in caught)
+    assert vfr.poll_faults() == 0
+
+
+@pytest.mark.gpu
 def test_bilstm_tile_shapes_agree(vfr, oracle):
     """The fused LSTM step picks 32-, 64- or 128-row tiles by batch size; all are the same chains.  Forced either way on one
     batch: identical bits to each other and (on the rows the oracle is run for) to the oracle."""

@@ -949,6 +949,68 @@ __global__ __launch_bounds__(1024) void lstm_seq_rescue_kernel(SeqLstm a, unsign
         if (fault_word_host) __hip_atomic_fetch_or(fault_word_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+// ---- rescue of the multi-step kernel (gemm.hip: lstm_steps_mfma_kernel) ------------------------------------------------------
+// Same contract as above for the big-batch form: one empty launch normally; when the error word is raised the final state of
+// EVERY GEMM row is recomputed with no cross-workgroup dependency -- one workgroup per row, thread = hidden unit, the four
+// gate chains of its unit started from the projection table (column of (gate, unit) in the fused step's tile order) and
+// continued over h, k ascending, bias pair after the chain: the fused step's order, hence the oracle's bits.  A row of the
+// reverse direction that the fused path lets ride on the all-pad row is simply stepped through its own pad tokens here (the
+// same tokens, the same state).  Slow (every workgroup streams W_hh per step) and rare.
+struct StepsRescue {
+    const float *ptab; size_t pdir; int NP;          // projection tables [2][vocab, NP]
+    const int *tokidx;                                // [T][R]
+    const float *Whh[2], *bih[2], *bhh[2];
+    float *hout;                                      // [R, 2H] final state (direction d at column d*H)
+    unsigned *err;
+    int R, T, H;
+};
+__global__ __launch_bounds__(1024) void lstm_steps_rescue_kernel(StepsRescue a, unsigned *fault_word_host)
+{
+    if (*a.err == 0u) return;
+    extern __shared__ __attribute__((aligned(16))) float seq_lds[];
+    float *hs = seq_lds;                              // [H] the previous step's h
+    const int m = blockIdx.x, u = threadIdx.x, H = a.H;
+    const bool on = u < H;
+    const int uc = on ? u : H - 1;
+    const int pcol = (uc >> 5) * 128 + ((uc >> 4) & 1) * 64 + (uc & 15);      // + 16 * gate
+    for (int d = 0; d < 2; ++d) {
+        float bsum[4], cst = 0.0f, hn = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bsum[g] = a.bih[d][g * H + uc] + a.bhh[d][g * H + uc];
+        for (int step = 0; step < a.T; ++step) {
+            const int t = d ? a.T - 1 - step : step;
+            const float *prow = a.ptab + (size_t)d * a.pdir + (size_t)a.tokidx[(size_t)t * a.R + m] * a.NP + pcol;
+            float acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = prow[16 * g];
+            if (on && step > 0)
+                for (int k4 = 0; k4 < H / 4; ++k4) {
+                    const float4 x = *reinterpret_cast<const float4 *>(hs + 4 * k4);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 w = *reinterpret_cast<const float4 *>(a.Whh[d] + ((size_t)g * H + u) * H + 4 * k4);
+                        acc[g] = __builtin_fmaf(x.x, w.x, acc[g]); acc[g] = __builtin_fmaf(x.y, w.y, acc[g]);
+                        acc[g] = __builtin_fmaf(x.z, w.z, acc[g]); acc[g] = __builtin_fmaf(x.w, w.w, acc[g]);
+                    }
+                }
+            const float ig = c_sigmoidf(acc[0] + bsum[0]);
+            const float fg = c_sigmoidf(acc[1] + bsum[1]);
+            const float gg = c_tanhf(acc[2] + bsum[2]);
+            const float og = c_sigmoidf(acc[3] + bsum[3]);
+            cst = __builtin_fmaf(fg, cst, ig * gg);
+            hn = og * c_tanhf(cst);
+            __syncthreads();                                      // every chain has read the old h
+            if (on) hs[u] = hn;
+            __syncthreads();
+        }
+        if (on) a.hout[(size_t)m * 2 * H + (size_t)d * H + u] = hn;
+        __syncthreads();
+    }
+    if (m == 0 && u == 0) {
+        atomicOr(a.err, 2u);
+        if (fault_word_host) __hip_atomic_fetch_or(fault_word_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 static int launch_seq_rescue(const SeqLstm &a, hipStream_t st)
 {
     const size_t lds = ((size_t)a.E + 3 * (size_t)a.H) * sizeof(float);
@@ -977,6 +1039,7 @@ struct LstmWs {
     float *X, *gates, *c, *c2, *hcat, *hcat2, *hfinal, *xv, *wperm, *ptab, *wt;
     unsigned long long *hg;               // persistent sequence kernel: [16 B error word | 2 x 2 x B x H granules]
     int *tokidx;
+    unsigned *sync;                       // multi-step kernel: tickets, error word, completion counters (lstm_steps_sync_words)
     int64_t *tok_ext;
     int *len, *row_of, *xrow, *mcount, *hist;
     size_t total;
@@ -1007,6 +1070,7 @@ static LstmWs carve(void *base, int64_t B, int T, int E, int H, int vocab)
         w.wperm = take(2 * np * E);
         w.ptab = take(2 * (size_t)vocab * np);
         w.tokidx = reinterpret_cast<int *>(take_b(R * T * sizeof(int)));
+        w.sync = reinterpret_cast<unsigned *>(take_b(lstm_steps_sync_words((int64_t)R, T) * sizeof(unsigned)));
     }
     if (B <= 4) w.wt = take((size_t)2 * (E + H) * 4 * H);       // k-major weights of the vector-chain step (a few queries)
     if (B <= 64) w.hg = reinterpret_cast<unsigned long long *>(take_b(16 + (size_t)4 * B * H * sizeof(unsigned long long)));
@@ -1153,11 +1217,12 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
     const int64_t R = B + 1;                                // GEMM rows: row 0 = all-pad query, then queries by length
     // tokens + one all-pad query -> embeddings of R queries
     {
-        const vfr::FillJob jobs[4] = {{w.tok_ext, tokens, (size_t)B * T * sizeof(int64_t), 0u},
+        const vfr::FillJob jobs[5] = {{w.tok_ext, tokens, (size_t)B * T * sizeof(int64_t), 0u},
                                       {w.tok_ext + (size_t)B * T, nullptr, (size_t)T * sizeof(int64_t), 0u},
                                       {w.c, nullptr, (size_t)2 * R * H * sizeof(float), 0u},
-                                      {w.hcat, nullptr, (size_t)R * 2 * H * sizeof(float), 0u}};
-        if (int rc = vfr::fill_regions(jobs, 4, st)) return rc;                     // one launch instead of a copy and three memsets
+                                      {w.hcat, nullptr, (size_t)R * 2 * H * sizeof(float), 0u},
+                                      {w.sync, nullptr, w.sync ? vfr::lstm_steps_sync_words(R, T) * sizeof(unsigned) : 0, 0u}};
+        if (int rc = vfr::fill_regions(jobs, w.sync ? 5 : 4, st)) return rc;        // one launch instead of a copy and three memsets
     }
     const bool fused = vfr::opt_gemm() != 0 && (E % 4) == 0 && (H % 4) == 0 &&
                        ((((uintptr_t)Wih_f) | ((uintptr_t)Whh_f) | ((uintptr_t)Wih_b) | ((uintptr_t)Whh_b)) & 15) == 0;
@@ -1194,7 +1259,26 @@ int vfr_bilstm_final_f32(const int64_t *tokens, int64_t B, int T, const float *e
                            vocab, w.tokidx);
         VFR_CHECK_LAUNCH("token_index_kernel");
     }
-    if (fused) {
+    if (fused && table && w.sync && H <= 1024 && vfr::lstm_steps_supported(R, H)) {
+        // ALL T steps of both directions in one launch (gemm.hip: lstm_steps_mfma_kernel): no partial round of workgroups at
+        // the end of every step, no launch gap between steps.  Three rotating state buffers (the third pair lives in the
+        // generic path's gates array, unused here); the final state is in buffer T % 3.
+        float *hbuf[3] = {w.hcat, w.hcat2, w.gates + (size_t)2 * R * H}, *cbuf[3] = {w.c, w.c2, w.gates};
+        vfr::GemmArgs g[2]{};
+        for (int d = 0; d < 2; ++d) {
+            g[d].A2 = hbuf[0] + (size_t)d * H; g[d].lda2 = 2 * H; g[d].W2 = Whh[d]; g[d].ldw2 = H; g[d].K2 = H;
+            g[d].bias = bih[d]; g[d].bias2 = bhh[d]; g[d].M = R; g[d].N = G;
+            g[d].lstm_ldh = 2 * H; g[d].lstm_H = H; g[d].site = vfr::SITE_GEMM_LSTM_REC;
+            g[d].lstm_xrow = nullptr; g[d].lstm_mcount = d ? w.mcount : nullptr;
+            g[d].Cin = w.ptab + (size_t)d * vocab * NP; g[d].ldc = NP;
+        }
+        if (int rc = vfr::lstm_steps_run(g[0], g[1], hbuf, cbuf, w.tokidx, w.mcount, w.sync, T, st)) return rc;
+        h_sorted = hbuf[T % 3];
+        // no-op unless the launch gave up (a bug or a lost workgroup): then every row is re-encoded on its own (never NaN)
+        vfr::StepsRescue ra{w.ptab, (size_t)vocab * NP, (int)NP, w.tokidx, {Whh[0], Whh[1]}, {bih[0], bih[1]}, {bhh[0], bhh[1]}, h_sorted, w.sync + 8, (int)R, T, H};
+        hipLaunchKernelGGL(vfr::lstm_steps_rescue_kernel, dim3((unsigned)R), dim3(1024), (size_t)H * sizeof(float), st, ra, vfr::fault_word());
+        VFR_CHECK_LAUNCH("lstm_steps_rescue_kernel");
+    } else if (fused) {
         // one MFMA launch per time step for both directions: K = [x_t (E) | h (H)], gate epilogue fused; the reverse
         // direction only touches the rows that have reached a real token (lstm_mcount), the rest ride on row 0
         float *hin = w.hcat, *hout = w.hcat2, *cin = w.c, *cout = w.c2;

@@ -10,6 +10,9 @@
 // (model/models.py:40-47), BERT-branch Linear (:31), VGG fc6/fc7 (get_rgb_features.py:126).
 #include "vfr_common.h"
 #include <type_traits>
+#include <vector>
+#include <cstdlib>
+#include <cstdio>
 #include "vfr_math.h"
 
 namespace vfr {
@@ -100,6 +103,9 @@ __global__ __launch_bounds__(256) void gemm_nt_valu(GemmArgs g)
 #define VFR_GEMM_PIPE 1      // 1: K-tile loop software-pipelined across the tile boundary (see the main loop); 0: the plain loop
 #endif
 #ifndef VFR_LSTM_DEPTH
+#ifndef VFR_LSTM_CELL_EARLY
+#define VFR_LSTM_CELL_EARLY 1   // 1: the gate epilogue's loads (previous cell state, biases) are requested at the head of the tile; 0: at the head of the epilogue
+#endif
 #define VFR_LSTM_DEPTH 1     // fragment prefetch distance (k-slices) of the fused LSTM step; the other MFMA kernels use 2
 #endif
 #ifndef VFR_LSTM_WAVES
@@ -171,9 +177,16 @@ __device__ unsigned long long g_gemm_stamps[4];
 // written into the interior of a tensor padded the same way (pooled size under EPI_POOL2).  Every tap of every output pixel then
 // reads real memory holding the right value -- zero outside the image -- so the loader needs no tap mask, no address select and
 // no zero-fill select: like the dense loop, no vector ALU instruction per K-tile (32 per 128 MFMAs in the masked form).
-template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false, bool NARROW = false, bool TRAIN = false, bool CFAST = false, bool LFAST = false, bool CHALO = false>
-__device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
+// MULTI = the LFAST step as ONE TASK of the multi-step kernel (lstm_steps_mfma_kernel below): the tile (task_by, task_m0) comes
+// from the task decode, and every byte of recurrent state -- h (the staged A operand, the remainder fragments), the previous
+// cell state, the stores of the new h / c -- moves with AGENT-scope accesses (sc1: write-through stores, loads that do not
+// trust this XCD's L2), because the producer of a row's h ran on another XCD in the SAME launch.  The weights and the
+// projection table are read-only and keep the plain (L2-resident) path.
+typedef unsigned int vfr_u32x4 __attribute__((ext_vector_type(4)));
+template <bool VEC, bool CONV, bool LSTM = false, int MI = 2, bool PP = false, bool NARROW = false, bool TRAIN = false, bool CFAST = false, bool LFAST = false, bool CHALO = false, bool MULTI = false>
+__device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g, int task_by = 0, int64_t task_m0 = 0, int task_tid = 0)
 {
+    static_assert(!MULTI || (LFAST && !TRAIN), "MULTI: the table-start LSTM step inside the multi-step kernel");
     static_assert(!CFAST || CONV, "CFAST: the convolution loader for C_in a multiple of 32");
     static_assert(!CHALO || CFAST, "CHALO: the scalar-tap loader on halo-padded activations");
     static_assert(!LFAST || (LSTM && !PP), "LFAST: the table-start LSTM step");
@@ -200,12 +213,14 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     __shared__ int otab_s[CHALO ? TBM : 1];              // CHALO: padded output pixel of every tile row (pooled pixel under EPI_POOL2)
     const int grp = PP ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // tile group of this wave
     float *lds = lds_all + grp * NBUF * BUF_FLOATS;
-    const int tid = PP ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = PP ? (int)(threadIdx.x & 255) : MULTI ? task_tid : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = NARROW ? wave : wave >> 1, wn = NARROW ? 0 : wave & 1;
     int64_t m0 = (int64_t)(PP ? blockIdx.x * 2 + grp : blockIdx.x) * TBM;
     int n0 = blockIdx.y * BN;
     int by = blockIdx.y;                                 // column tile (LSTM step: 4 gates x 32 units)
     bool active = true;                                  // PP: a group without a tile still takes part in the barriers
+    if constexpr (MULTI) { by = task_by; m0 = task_m0; }
+    else
     if (LSTM && g.xcd_cols > 0) {
         // XCD-aware order of the fused step (1-D grid per direction; workgroup L runs on XCD L % 8): each XCD owns xcd_cols
         // adjacent column tiles -- its 2 MB slice of W_hh stays in its 4 MB L2 for the whole launch -- and walks the row
@@ -503,11 +518,25 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // the finite w re-read beside them), and so are the lanes past the end of a segment shorter than one tile.
     const int nk1 = (g.K + MBK - 1) / MBK;
     bool zq = false;
+    // MULTI: buffer resource over the h operand (raw buffer, 32-bit byte offsets: lstm_steps_pair checks the 4 GB bound)
+    __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MULTI ? g.A2 : nullptr), 0, MULTI ? 0xFFFFFFFFu : 0u, 0x00020000);
     auto gload_seg = [&](int k0t, auto sc) {
         constexpr int S = decltype(sc)::value;
         if constexpr (LFAST) {           // one segment of whole K-tiles: scalar base + the thread's fixed offsets, nothing to select
             const char *ba = reinterpret_cast<const char *>(g.A2 + k0t);
             const char *bw = reinterpret_cast<const char *>(g.W2 + k0t);
+#ifdef VFR_MULTI_PLAIN_A     /* TIMING EXPERIMENT ONLY (incoherent: h may be read stale): the A operand through the plain L2 path */
+            if constexpr (false) {
+#else
+            if constexpr (MULTI) {       // h of the previous step, written in this launch by other XCDs: 16-byte loads at agent scope (sc1)
+#endif
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    asm volatile("" : "+v"(aoff2[i]));
+                    const vfr_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (int)aoff2[i], k0t * 4, 16);
+                    ra[S][i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < NA; ++i) { asm volatile("" : "+v"(aoff2[i])); ra[S][i] = *reinterpret_cast<const float4 *>(ba + aoff2[i]); }
 #pragma unroll
@@ -544,8 +573,13 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             const int64_t row = m0 + wm * (16 * TI_) + ti * 16 + (lane & 15);
             const int64_t ma = row < Mrows ? row : Mrows - 1;
             const float *pa = g.A2 + (ma >= Mprev ? 0 : ma) * g.lda2 + kb;
+            if constexpr (MULTI) {
+                tfa[0][ti] = __hip_atomic_load(pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tfa[1][ti] = ktail > 4 ? __hip_atomic_load(pa + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+            } else {
             tfa[0][ti] = pa[0];
             tfa[1][ti] = ktail > 4 ? pa[4] : 0.0f;
+            }
         }
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
@@ -654,6 +688,31 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
     // main loop over the FULL K-tiles, branch-free: iteration kt prefetches tile min(kt+1, last) (the final
     // iteration re-reads its own tile, which is harmless) so no control-flow join sits between the loads and the
     // MFMA block -- a join there makes the compiler drain vmcnt(0) before the first MFMA.
+    // Fused LSTM step: what the gate epilogue needs from memory -- the previous cell state of the lane's 4*TI cells and the four
+    // bias pairs of its unit -- is requested at the HEAD of the tile, beside the projection-table gather (one latency window,
+    // 12 registers held across the K-loop at 64 rows), not at the head of the epilogue, where nothing else of this wave is in
+    // flight to cover it.
+    constexpr int TIc = MI ? 2 * MI : 1;
+    float cprev[LSTM ? TIc : 1][4];
+    float bi = 0.f, bf = 0.f, bg = 0.f, bo = 0.f;
+    auto load_cell_inputs = [&]() {
+        if constexpr (LSTM) {
+            const int H = g.lstm_H, unit = by * 32 + wn * 16 + (lane & 15);
+            const int uc = unit < H ? unit : H - 1;
+            bi = g.bias[uc] + g.bias2[uc]; bf = g.bias[H + uc] + g.bias2[H + uc];
+            bg = g.bias[2 * H + uc] + g.bias2[2 * H + uc]; bo = g.bias[3 * H + uc] + g.bias2[3 * H + uc];
+#pragma unroll
+            for (int ti = 0; ti < TIc; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = m0 + wm * (16 * TIc) + ti * 16 + 4 * (lane >> 4) + r;
+                    const int64_t rc = row < Mrows ? row : Mrows - 1;
+                    if constexpr (MULTI) cprev[ti][r] = __hip_atomic_load(g.lstm_cin + (rc >= Mprev ? 0 : rc) * H + uc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else cprev[ti][r] = g.lstm_cin[(rc >= Mprev ? 0 : rc) * H + uc];
+                }
+        }
+    };
+    constexpr bool CELL_EARLY = LSTM && !PP && NBUF == 2 && VFR_GEMM_PIPE && VFR_LSTM_CELL_EARLY;
     auto gload_main = [&](int k0, auto sc) { if (LSTM) gload_seg(k0, sc); else if (CFAST) gload_conv_fast(k0, sc); else if (CONV) gload_conv(k0, sc); else gload_full(k0, sc); };
     if (PP) {
         // group g runs  C0 L1 C1 L2 ... C(nk-1)  delayed by g phases;  Ck = MFMA block on K-tile k (LDS), Lk = K-tile k from
@@ -697,6 +756,7 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         // dependent load rounds whose latency would otherwise stand alone at the head of every tile)
         if (nk > 0) gload_main(0, S0);
         init_acc();
+        if constexpr (CELL_EARLY) load_cell_inputs();
         // Accumulators that start from LOADED values (C-in, the LSTM projection-table gather) must have landed before the loop is
         // entered: otherwise the waitcnt pass, merging the loop-entry state into the loop header, guards the first MFMAs of EVERY
         // trip with vmcnt(3) .. vmcnt(0) -- which on the back edge drains the staging loads requested five slices earlier, i.e. the
@@ -824,21 +884,12 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
         const int H = g.lstm_H, unit = by * 32 + wn * 16 + l15;
         const bool valid = unit < H;
         const int uc = valid ? unit : H - 1;
-        const float bi = g.bias[uc] + g.bias2[uc], bf = g.bias[H + uc] + g.bias2[H + uc];
-        const float bg = g.bias[2 * H + uc] + g.bias2[2 * H + uc], bo = g.bias[3 * H + uc] + g.bias2[3 * H + uc];
+        if constexpr (!CELL_EARLY) load_cell_inputs();
         // batched and branch-free: the previous-cell loads first (clamped addresses), then 4*TI independent gate evaluations
         // in ONE basic block (the asm pins the results ahead of the predicated stores; hipcc otherwise sinks each cell's ~190
         // instructions into its own store predicate, one serial dependency chain after the other)
-        float cprev[TI][4], cnew[TI][4], hnew[TI][4];
+        float cnew[TI][4], hnew[TI][4];
         float gsave[TRAIN ? TI : 1][4][4];
-#pragma unroll
-        for (int ti = 0; ti < TI; ++ti)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq + r;
-                const int64_t rc = row < Mrows ? row : Mrows - 1;
-                cprev[ti][r] = g.lstm_cin[(rc >= Mprev ? 0 : rc) * H + uc];
-            }
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -858,8 +909,13 @@ __device__ __forceinline__ void gemm_nt_mfma_body(const GemmArgs &g)
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = m0 + wm * (16 * TI) + ti * 16 + 4 * lq + r;
                 if (valid && row < Mrows) {
+                    if constexpr (MULTI) {
+                        __hip_atomic_store(g.lstm_c + row * H + unit, cnew[ti][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(g.lstm_h + row * g.lstm_ldh + unit, hnew[ti][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
                     g.lstm_c[row * H + unit] = cnew[ti][r];
                     g.lstm_h[row * g.lstm_ldh + unit] = hnew[ti][r];
+                    }
                     if constexpr (TRAIN) {
                         float *g4 = g.lstm_gates + row * 4 * H + unit;
                         g4[0] = gsave[ti][r][0]; g4[H] = gsave[ti][r][1]; g4[2 * H] = gsave[ti][r][2]; g4[3 * H] = gsave[ti][r][3];
@@ -1002,6 +1058,193 @@ __global__ __launch_bounds__(256, MI <= 1 ? 3 : VFR_LSTM_WAVES) void lstm_step_m
     const GemmArgs g = gp.p[blockIdx.z];      // private copy, see gemm_nt_mfma_pair
     gemm_nt_mfma_body<true, false, true, MI, false, false, false, false, LFAST>(g);
 }
+// ---- all T steps of both directions in ONE launch ------------------------------------------------------------------------
+// One launch per time step ends every step with a partial round of workgroups (3.3 .. 6.6 rounds of the chip's 768 slots per
+// step at 5 000 queries: +-5 % per step in profiles/r4t_lstm_steps.txt; 1.1 rounds at a rank's 626 rows: half the chip idle
+// half the time) and starts the next one 6 us later with every CU in its prologue at once.  Here the (step, direction, row
+// tile, column tile) tasks of the whole sequence are ONE ordered list per XCD group (step-major; inside a step the order of
+// the per-step launch: forward row tiles, then the reverse direction's active ones, the group's column tiles fastest -- its
+// slice of W_hh stays in its L2), and 3 workgroups per CU draw tickets from their group's counter until the list is empty.
+// A task of step s needs h / c of step s - 1 for ITS rows (all column tiles of the same row tile: the K dimension) and, in the
+// reverse direction, for row tile 0 (the shared all-pad row); it waits until the completion counters of those row tiles
+// read `ncol`.  The state rotates through THREE buffers (step s reads s % 3, writes (s + 1) % 3), and a task also waits for
+// ALL of step s - 2 (whose reads are the last users of the buffer it writes).
+// No deadlock, whatever is resident: every dependency points to an earlier step, every group's list is sorted by step, and
+// a ticket is only ever held by a workgroup that is running -- so the earliest unfinished task of the whole launch is always
+// either running or next in line for a running workgroup.  (Nothing here needs the grid to be co-resident: unlike the
+// register-resident sequence kernels a workgroup never waits for one that has not started.)  The waits are bounded all
+// the same (a bug or a lost workgroup must not hang the device): on expiry the error word is raised, every workgroup leaves,
+// and the rescue kernel behind the launch (bilstm.hip) re-encodes the batch.
+// Coherence: the producer of a row's h ran on another XCD, whose L2 this one does not snoop -- see MULTI in the kernel body.
+struct LstmSteps {
+    GemmArgs p[2];                 // step-invariant arguments per direction (W2 / ldw2 / biases / Cin = the projection table / M = rows ...)
+    float *hbuf[3], *cbuf[3];      // rotating state: h [R, 2H] (direction d at column d*H), c [2][R, H]; buffer 0 zeroed
+    const int *tokidx;             // [T][R] projection-table row of GEMM row m at time t
+    const int *mcount;             // reverse direction: active rows per step
+    unsigned *sync;                // [8 tickets | error word | pad to 16 | T step counters | T x 2 x rt_max row-tile counters], zeroed
+    int T, cpx, ncol, rt_max;
+    unsigned max_spins;
+    int fault_task;                // TEST HOOK (-1: off): this ticket of group 0 never signals its completion
+};
+#ifdef VFR_STEPS_STAMPS
+__device__ unsigned long long g_steps_stamps[8];
+__device__ unsigned long long g_steps_waits[32];
+#define SSTAMP(i) { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); sst[i] += t_ - st0; st0 = t_; } }
+#else
+#define SSTAMP(i)
+#endif
+template <int MI>
+__global__ __launch_bounds__(256, MI <= 1 ? 3 : 2) void lstm_steps_mfma_kernel(LstmSteps a)
+{
+#ifdef VFR_STEPS_STAMPS
+    unsigned long long sst[6] = {0, 0, 0, 0, 0, 0}, st0 = __builtin_amdgcn_s_memtime();
+#endif
+    constexpr int TBM = MI ? 64 * MI : 32;
+    __shared__ unsigned s_next;
+    __shared__ int s_dead;
+    const int tid = threadIdx.x;
+    const unsigned x = blockIdx.x & 7u;
+    unsigned *tick = a.sync + x, *err = a.sync + 8, *stepdone = a.sync + 16, *done = a.sync + 16 + a.T;
+    const int R = (int)a.p[0].M, rtf = (R + TBM - 1) / TBM, cpx = a.cpx, T = a.T;
+    // (mcount is written by an earlier kernel; loaded through the vector path here, its values are pinned to SGPRs: everything
+    // below -- the step, the tile, every pointer of the task -- must stay scalar, or the body's buffer loads are wrapped in
+    // waterfall loops and its K-tile counter lives in a VGPR)
+    auto rtr_of = [&](int s) { return __builtin_amdgcn_readfirstlane((a.mcount[s] + TBM - 1) / TBM); };
+    // position in the group's list: step `cur`, whose tasks are tickets [base, base + ncur)
+    int cur = 0;
+    unsigned base = 0, ncur = (unsigned)((rtf + rtr_of(0)) * cpx);
+    auto advance = [&](unsigned n, int &c, unsigned &b, unsigned &nc) {      // -> the step ticket n belongs to (c == T: past the end)
+        while (c < T && n >= b + nc) {
+            b += nc; ++c;
+            if (c < T) nc = (unsigned)((rtf + rtr_of(c)) * cpx);
+        }
+        c = __builtin_amdgcn_readfirstlane(c);
+        b = __builtin_amdgcn_readfirstlane(b);
+        nc = __builtin_amdgcn_readfirstlane(nc);
+    };
+    struct Deps { const unsigned *p[3]; unsigned want[3]; };
+    // what ticket n of step c waits for: its row tile and (reverse direction) row tile 0 at step c - 1, all of step c - 2
+    auto deps_of = [&](unsigned n, int c, unsigned b) -> Deps {
+        Deps q{{nullptr, nullptr, nullptr}, {0u, 0u, 0u}};
+        unsigned j = n - b;
+        const int d = j >= (unsigned)(rtf * cpx) ? 1 : 0;
+        if (d) j -= (unsigned)(rtf * cpx);
+        const int rt = (int)(j / (unsigned)cpx), by = (int)(x * (unsigned)cpx + j % (unsigned)cpx);
+        if (by >= a.ncol || c == 0) return q;
+        const unsigned *dprev = done + ((size_t)(c - 1) * 2 + d) * a.rt_max;
+        if (rt < (d ? rtr_of(c - 1) : rtf)) { q.p[0] = dprev + rt; q.want[0] = (unsigned)a.ncol; }
+        if (d && rt != 0) { q.p[1] = dprev; q.want[1] = (unsigned)a.ncol; }
+        if (c >= 2) { q.p[2] = stepdone + (c - 2); q.want[2] = (unsigned)((rtf + rtr_of(c - 2)) * a.ncol); }
+        return q;
+    };
+    auto wait_ge = [&](const unsigned *ptr, unsigned target) -> bool {
+        unsigned spins = 0;
+        while (__hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 63u) == 0u && (spins > a.max_spins || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) return false;
+        }
+        return true;
+    };
+    if (tid == 0) {
+        // the first ticket, its dependencies the slow way
+        const unsigned n0 = atomicAdd(tick, 1u);
+        int c = 0; unsigned b = 0, nc = ncur;
+        advance(n0, c, b, nc);
+        bool ok = true;
+        if (c < T) {
+            const Deps q = deps_of(n0, c, b);
+            for (int i = 0; i < 3; ++i) if (ok && q.p[i]) ok = wait_ge(q.p[i], q.want[i]);
+        }
+        if (!ok) atomicOr(err, 1u);
+        s_dead = ok ? 0 : 1;
+        s_next = n0;
+    }
+    __syncthreads();
+    unsigned n = __builtin_amdgcn_readfirstlane(s_next);
+    for (;;) {
+        SSTAMP(0)
+        if (__builtin_amdgcn_readfirstlane(s_dead)) break;
+        advance(n, cur, base, ncur);
+        if (cur >= T) break;
+        unsigned j = n - base;
+        const int d = j >= (unsigned)(rtf * cpx) ? 1 : 0;
+        if (d) j -= (unsigned)(rtf * cpx);
+        const int rt = (int)(j / (unsigned)cpx), by = (int)(x * (unsigned)cpx + j % (unsigned)cpx);
+        const bool valid = by < a.ncol;
+        SSTAMP(1)
+        if (valid) {
+            GemmArgs g = a.p[d];
+            const int t = d ? T - 1 - cur : cur;
+            float *hin = a.hbuf[cur % 3], *hout = a.hbuf[(cur + 1) % 3];
+            const int H = g.lstm_H;
+            g.A2 = hin + (size_t)d * H; g.A = g.A2;
+            g.lstm_h = hout + (size_t)d * H;
+            g.lstm_cin = a.cbuf[cur % 3] + (size_t)d * R * H;
+            g.lstm_c = a.cbuf[(cur + 1) % 3] + (size_t)d * R * H;
+            g.lstm_tok = a.tokidx + (size_t)t * R;
+            g.lstm_step = cur;
+            g.K2 = cur == 0 ? 0 : H;                 // h_0 = 0: the first step is its table gather + gate epilogue (see bilstm.hip)
+            // (the thread index is made opaque per task: everything the body derives from it would otherwise be hoisted out of the
+            // task loop and held in registers across it -- 40 more VGPRs than the per-step kernel, spilled at three workgroups per CU)
+            int tid_task = tid;
+            asm volatile("" : "+v"(tid_task));
+            gemm_nt_mfma_body<true, false, true, MI, false, false, false, false, true, false, true>(g, by, (int64_t)rt * TBM, tid_task);
+        }
+        SSTAMP(2)
+        // The next ticket is drawn only now (a ticket drawn before the task would sit idle for the task's whole duration, and the
+        // same row tile of the next step, on all eight groups, with it), and the next task's dependency counters are requested
+        // BEFORE this task's stores are drained: both round trips ride on the drain (read one after the other behind the
+        // barrier, three dependent round trips cost 7 % of a 5 000-query pass).
+        Deps q{{nullptr, nullptr, nullptr}, {0u, 0u, 0u}};
+        unsigned seen[3] = {0u, 0u, 0u};
+        int c2 = cur;
+        unsigned nxt = 0;
+        if (tid == 0) {
+            nxt = atomicAdd(tick, 1u);
+            unsigned b2 = base, nc2 = ncur;
+            advance(nxt, c2, b2, nc2);
+            if (c2 < T) {
+                q = deps_of(nxt, c2, b2);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) if (q.p[i]) seen[i] = __hip_atomic_load(q.p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this wave's write-through stores of h / c have been acknowledged
+        __syncthreads();
+        SSTAMP(3)
+        if (tid == 0) {
+            if (valid && !(a.fault_task >= 0 && x == 0u && n == (unsigned)a.fault_task)) {
+                __hip_atomic_fetch_add(done + ((size_t)cur * 2 + d) * a.rt_max + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(stepdone + cur, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bool ok = true;
+            if (c2 < T) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) if (ok && q.p[i] && seen[i] < q.want[i]) {
+#ifdef VFR_STEPS_STAMPS
+                    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
+                    ok = wait_ge(q.p[i], q.want[i]);
+#ifdef VFR_STEPS_STAMPS
+                    atomicAdd(&g_steps_waits[i], 1ull); atomicAdd(&g_steps_waits[3 + i], __builtin_amdgcn_s_memtime() - w0);
+                    if (c2 < 20) atomicAdd(&g_steps_waits[8 + c2], 1ull);
+#endif
+                }
+                if (!ok) atomicOr(err, 1u);
+            }
+            s_dead = ok ? 0 : 1;
+            s_next = nxt;
+        }
+        SSTAMP(4)
+        __syncthreads();                             // the next task's dependencies are met (and every wave has left this task's LDS tiles)
+        n = __builtin_amdgcn_readfirstlane(s_next);
+        SSTAMP(5)
+    }
+#ifdef VFR_STEPS_STAMPS
+    if (tid == 0) { for (int i = 0; i < 6; ++i) atomicAdd(&g_steps_stamps[i], sst[i]); atomicAdd(&g_steps_stamps[6], 1ull); }
+#endif
+}
+
 template <int MI>
 __global__ __launch_bounds__(256, MI <= 1 ? 3 : 2) void lstm_step_train_mfma_pair(GemmPair gp)
 {
@@ -1135,6 +1378,90 @@ int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st)
         const double tot = (double)h[0] + h[1] + h[2];
         fprintf(stderr, "[gemm stamps] step %d: tiles so far %llu  prologue %.1f%%  main loop %.1f%%  epilogue %.1f%%  (%.0f ticks per wave-tile)\n",
                 g0.lstm_step, h[3], 100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, tot / (4.0 * h[3]));
+    }
+#endif
+    return VFR_OK;
+}
+
+// all T steps in one launch (lstm_steps_mfma_kernel); g0 / g1 carry the step-invariant arguments of the two directions
+bool lstm_steps_supported(int64_t R, int H)
+{
+    const int rem = H % MBK;
+    // (the cross-check switches of the per-step launch -- general K-loop, first step with its recurrent part, launch order, 128-row
+    // tiles -- select the per-step path)
+    return opt_lstm_multi() && opt_lstm_fast() && opt_lstm_skip0() && opt_lstm_xcd() && bool(VFR_GEMM_PIPE) && VFR_LSTM_NBUF == 2 && (H % 4) == 0 && H >= MBK && (rem == 0 || (H > MBK && rem <= 8)) &&
+           ((R + 1) * 2 * (int64_t)H + MBK) * 4 < (1ll << 32);
+}
+size_t lstm_steps_sync_words(int64_t R, int T) { return 16 + (size_t)T + (size_t)T * 2 * (size_t)cdiv(R, 32); }
+int lstm_steps_run(const GemmArgs &g0, const GemmArgs &g1, float *const hbuf[3], float *const cbuf[3], const int *tokidx, const int *mcount,
+                   unsigned *sync, int T, hipStream_t st)
+{
+    if (g0.M == 0 || T == 0) return VFR_OK;
+    for (const GemmArgs *g : {&g0, &g1}) {
+        VFR_REQUIRE(g->W2 && g->bias && g->bias2 && g->Cin && g->lstm_H > 0 && tokidx && mcount && sync, VFR_EINVAL, "lstm_steps_run: bad argument");
+        VFR_REQUIRE(lstm_steps_supported(g->M, g->lstm_H), VFR_EUNSUPPORTED, "lstm_steps_run: shape not supported (use the per-step launches)");
+        VFR_REQUIRE(((g->lda2 | g->ldw2) & 3) == 0 && (((uintptr_t)g->W2) & 15) == 0 && (4ll * g->lstm_H * g->ldw2 + MBK) * 4 < (1ll << 32), VFR_EUNSUPPORTED,
+                    "lstm_steps_run: operand strides must be multiples of 4 floats, 16-byte aligned, under 4 GB");
+    }
+    ProfScope prof(g0.site, st);
+    LstmSteps a{};
+    a.p[0] = g0; a.p[1] = g1;
+    for (int d = 0; d < 2; ++d) { a.p[d].K = 0; a.p[d].W = a.p[d].W2; a.p[d].ldw = a.p[d].ldw2; a.p[d].lda = a.p[d].lda2; a.p[d].xcd_cols = 0; }
+    for (int i = 0; i < 3; ++i) { a.hbuf[i] = hbuf[i]; a.cbuf[i] = cbuf[i]; }
+    a.tokidx = tokidx; a.mcount = mcount; a.sync = sync; a.T = T;
+    a.ncol = (int)cdiv(g0.lstm_H, 32); a.cpx = (int)cdiv(a.ncol, 8);
+    const int tile = opt_lstm_tile() == 3 || (opt_lstm_tile() == 0 && g0.M <= 700) ? 3 : opt_lstm_tile() == 2 ? 2 : 1;      // 32-row tiles for small batches (as lstm_step_pair)
+    a.rt_max = (int)cdiv(g0.M, 32);
+    a.fault_task = opt_lstm_persist_fault();
+    a.max_spins = a.fault_task >= 0 ? 1u << 15 : 1u << 22;       // x (~1 us per poll): seconds -- only ever reached through a bug or a lost workgroup
+    const int64_t rows = tile == 3 ? 32 : tile == 2 ? 128 : 64;
+    const int64_t per_step_max = 2 * cdiv(g0.M, rows) * a.cpx * 8;
+    int64_t slots = (int64_t)device_cu_count() * (tile == 2 ? 2 : 3) / 8 * 8;
+    if (slots > per_step_max * T) slots = per_step_max * T;
+    if (slots < 8) slots = 8;
+    if (tile == 3)      hipLaunchKernelGGL(lstm_steps_mfma_kernel<0>, dim3((unsigned)slots), dim3(256), 0, st, a);
+    else if (tile == 2) hipLaunchKernelGGL(lstm_steps_mfma_kernel<2>, dim3((unsigned)slots), dim3(256), 0, st, a);
+    else                hipLaunchKernelGGL(lstm_steps_mfma_kernel<1>, dim3((unsigned)slots), dim3(256), 0, st, a);
+    VFR_CHECK_LAUNCH("lstm_steps_mfma_kernel");
+#if defined(VFR_STEPS_STAMPS) || defined(VFR_GEMM_STAMPS)      /* timing builds only (tools/build_variant.sh): counters and phase stamps of the launch */
+    if (getenv("VFR_STEPS_DEBUG")) {
+        const size_t nw = lstm_steps_sync_words(g0.M, T);
+        std::vector<unsigned> h(nw);
+        hipError_t e = hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), sync, nw * 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[steps debug] sync err %d (%s) grid %lld tile %d R %lld T %d ncol %d cpx %d rt_max %d\n  tickets:", (int)e, hipGetErrorString(e), (long long)slots, tile, (long long)g0.M, T, a.ncol, a.cpx, a.rt_max);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %u", h[i]);
+        fprintf(stderr, "\n  err %u\n  stepdone:", h[8]);
+        for (int i = 0; i < T; ++i) fprintf(stderr, " %u", h[16 + i]);
+        fprintf(stderr, "\n  done[0][0][..8]:");
+        for (int i = 0; i < 8 && i < a.rt_max; ++i) fprintf(stderr, " %u", h[16 + T + i]);
+        fprintf(stderr, "\n");
+#ifdef VFR_GEMM_STAMPS
+        {
+            unsigned long long h4[4], z4[4] = {0, 0, 0, 0};
+            (void)hipMemcpyFromSymbol(h4, HIP_SYMBOL(g_gemm_stamps), sizeof h4);
+            const double tot4 = (double)h4[0] + h4[1] + h4[2];
+            fprintf(stderr, "  body stamps: tiles %llu  prologue %.1f%%  main loop %.1f%%  epilogue %.1f%%  (%.0f ticks per wave-tile)\n",
+                    h4[3], 100 * h4[0] / tot4, 100 * h4[1] / tot4, 100 * h4[2] / tot4, tot4 / (4.0 * h4[3]));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), z4, sizeof z4);
+        }
+#endif
+#ifdef VFR_STEPS_STAMPS
+        unsigned long long hs[8];
+        (void)hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_steps_stamps), sizeof hs);
+        double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)hs[i];
+        fprintf(stderr, "  stamps (thread 0 of %llu workgroups, 100 MHz ticks): loop top %.1f%%  decode %.1f%%  body %.1f%%  dep request + drain + barrier %.1f%%  signal + dep wait %.1f%%  barrier %.1f%%   total %.0f ticks per workgroup\n",
+                hs[6], 100 * hs[0] / tot, 100 * hs[1] / tot, 100 * hs[2] / tot, 100 * hs[3] / tot, 100 * hs[4] / tot, 100 * hs[5] / tot, tot / (double)hs[6]);
+        unsigned long long hw[32], zw[32] = {};
+        (void)hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_steps_waits), sizeof hw);
+        fprintf(stderr, "  slow-path waits: row tile %llu (%.0f ticks each)  row tile 0 %llu (%.0f)  step-2 %llu (%.0f); by step:", hw[0], hw[0] ? (double)hw[3] / hw[0] : 0.0,
+                hw[1], hw[1] ? (double)hw[4] / hw[1] : 0.0, hw[2], hw[2] ? (double)hw[5] / hw[2] : 0.0);
+        for (int i = 0; i < 20; ++i) fprintf(stderr, " %llu", hw[8 + i]);
+        fprintf(stderr, "\n");
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_steps_waits), zw, sizeof zw);
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_steps_stamps), z, sizeof z);
+#endif
     }
 #endif
     return VFR_OK;

@@ -30,6 +30,7 @@ static std::atomic<int> g_opt_smallq_select{1};    // 1: the few-queries path ta
 static std::atomic<int> g_opt_lstm_persist_min{2}; // batches ABOVE this many queries (up to 32, the model's shape) take the single-launch MFMA sequence kernel; 32: never
 static std::atomic<int> g_opt_lstm_persist_fault{-1}; // TEST HOOK: workgroup of the single-launch sequence kernels that withholds its h of step 1 (-1: none)
 static std::atomic<int> g_opt_lstm_persist_max{32}; // ... and up to this many.  33 .. 64 are possible (two parts of <= 32 queries taking turns on the same resident weights): bit-identical, but 0.70 ms per 64-query pass against 0.62 for the tile steps (the two-part kernel's 275 weight registers + two parts' state spill): off by default
+static std::atomic<int> g_opt_lstm_multi{0};       // EXPERIMENT (off): 1 = all T steps of the fused BiLSTM in ONE launch (gemm.hip: lstm_steps_mfma_kernel; 128-row tiles with lstm_tile 2) -- same bits; measured no faster than one launch per step at 5 000 queries, 4-5 % faster around 2 500 (HISTORY.md)
 static std::atomic<int> g_opt_lstm_fast{1};        // 1: the table-start LSTM step without selects in its K-loop where the launch qualifies; 0: always the general form (cross-check)
 static std::atomic<int> g_opt_vgg_halo{1};         // 1: the VGG stack on halo-padded activations where its shape allows (select-free convolution loader); 0: unpadded (cross-check)
 static std::atomic<int> g_opt_lstm_small4{1};      // 1: a single query of the model's shape takes the four-wave vector-chain step (weights streamed by three loader waves); 0: the one-wave step (cross-check)
@@ -42,7 +43,7 @@ struct Opt { const char *name; std::atomic<int> *v; };
 static const Opt g_opts[] = {
     {"gemm", &g_opt_gemm}, {"profile", &g_opt_profile}, {"score_fast", &g_opt_score_fast}, {"score_split", &g_opt_score_split},
     {"score_pre_b", &g_opt_score_pre_b}, {"score_smallq", &g_opt_score_smallq}, {"score_tasks", &g_opt_score_tasks}, {"lstm_skip0", &g_opt_lstm_skip0},
-    {"lstm_xcd", &g_opt_lstm_xcd}, {"gemm_small", &g_opt_gemm_small}, {"lstm_tile", &g_opt_lstm_tile}, {"lstm_small4", &g_opt_lstm_small4}, {"lstm_persist", &g_opt_lstm_persist}, {"lstm_persist_min", &g_opt_lstm_persist_min}, {"lstm_fast", &g_opt_lstm_fast}, {"lstm_persist_max", &g_opt_lstm_persist_max}, {"lstm_persist_fault", &g_opt_lstm_persist_fault}, {"vgg_fuse_pool", &g_opt_vgg_fuse_pool}, {"vgg_direct1", &g_opt_vgg_direct1}, {"vgg_halo", &g_opt_vgg_halo}, {"score_smallq_select", &g_opt_smallq_select}, {"gemm_pp", &g_opt_gemm_pp}, {"score_mfma_min", &g_opt_mfma_min}, {"lstm_small", &g_opt_lstm_small}, {"score_defer", &g_opt_score_defer}, {"score_sort", &g_opt_score_sort}, {"score_hist", &g_opt_score_hist},
+    {"lstm_xcd", &g_opt_lstm_xcd}, {"gemm_small", &g_opt_gemm_small}, {"lstm_tile", &g_opt_lstm_tile}, {"lstm_small4", &g_opt_lstm_small4}, {"lstm_persist", &g_opt_lstm_persist}, {"lstm_persist_min", &g_opt_lstm_persist_min}, {"lstm_fast", &g_opt_lstm_fast}, {"lstm_multi", &g_opt_lstm_multi}, {"lstm_persist_max", &g_opt_lstm_persist_max}, {"lstm_persist_fault", &g_opt_lstm_persist_fault}, {"vgg_fuse_pool", &g_opt_vgg_fuse_pool}, {"vgg_direct1", &g_opt_vgg_direct1}, {"vgg_halo", &g_opt_vgg_halo}, {"score_smallq_select", &g_opt_smallq_select}, {"gemm_pp", &g_opt_gemm_pp}, {"score_mfma_min", &g_opt_mfma_min}, {"lstm_small", &g_opt_lstm_small}, {"score_defer", &g_opt_score_defer}, {"score_sort", &g_opt_score_sort}, {"score_hist", &g_opt_score_hist},
 };
 
 struct ProfPair { int site; hipEvent_t a, b; };
@@ -102,6 +103,7 @@ int opt_lstm_small4() { return g_opt_lstm_small4; }
 int opt_lstm_persist() { return g_opt_lstm_persist; }
 int opt_lstm_persist_min() { return g_opt_lstm_persist_min; }
 int opt_lstm_fast() { return g_opt_lstm_fast; }
+int opt_lstm_multi() { return g_opt_lstm_multi; }
 int opt_lstm_persist_max() { return g_opt_lstm_persist_max; }
 int opt_lstm_persist_fault() { return g_opt_lstm_persist_fault; }
 int opt_vgg_fuse_pool() { return g_opt_vgg_fuse_pool; }
@@ -128,14 +130,17 @@ int opt_score_defer() { return g_opt_score_defer; }
 int opt_score_sort() { return g_opt_score_sort; }
 int opt_score_hist() { return g_opt_score_hist; }
 
-struct FillArgs { unsigned *dst[4]; const unsigned *src[4]; unsigned long long words[4]; unsigned value[4]; unsigned long long start[5]; };
+constexpr int FILL_MAX = 6;               // regions per launch
+struct FillArgs { unsigned *dst[FILL_MAX]; const unsigned *src[FILL_MAX]; unsigned long long words[FILL_MAX]; unsigned value[FILL_MAX]; unsigned long long start[FILL_MAX + 1]; };
 __global__ __launch_bounds__(256) void fill_regions_kernel(FillArgs a)
 {
     // 16 bytes per thread where the region allows (every region base the library fills is 256-byte aligned; a misaligned or odd
     // one falls back to words)
-    const unsigned long long total = a.start[4];
+    const unsigned long long total = a.start[FILL_MAX];
     for (unsigned long long i = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (unsigned long long)gridDim.x * 1024) {
-        const int r = i >= a.start[3] ? 3 : i >= a.start[2] ? 2 : i >= a.start[1] ? 1 : 0;
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < FILL_MAX; ++q) r = i >= a.start[q] ? q : r;      // (empty regions share their successor's start: the last match wins)
         const unsigned long long off = i - a.start[r];
         unsigned *d = a.dst[r] + off;
         const unsigned long long left = a.words[r] - off;
@@ -152,7 +157,8 @@ int fill_regions(const FillJob *jobs, int n, hipStream_t st)
 {
     FillArgs a{};
     unsigned long long total = 0;
-    for (int r = 0; r < 4; ++r) {
+    if (n > FILL_MAX) return fail(VFR_EINVAL, "fill_regions: %d regions > %d", n, FILL_MAX);
+    for (int r = 0; r < FILL_MAX; ++r) {
         a.start[r] = total;
         if (r < n && jobs[r].bytes) {
             if ((jobs[r].bytes & 3) || (((uintptr_t)jobs[r].dst) & 3) || (((uintptr_t)jobs[r].src) & 3) || !jobs[r].dst)
@@ -164,7 +170,7 @@ int fill_regions(const FillJob *jobs, int n, hipStream_t st)
             total += (a.words[r] + 3) / 4 * 4;
         }
     }
-    a.start[4] = total;
+    a.start[FILL_MAX] = total;
     if (total == 0) return VFR_OK;
     unsigned long long blocks = (total / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;

@@ -30,6 +30,7 @@ int opt_lstm_tile();
 int opt_lstm_small4();
 int opt_lstm_persist();
 int opt_lstm_fast();
+int opt_lstm_multi();
 int opt_lstm_persist_min();
 int opt_lstm_persist_max();
 int opt_lstm_persist_fault();
@@ -153,6 +154,14 @@ int gemm_nt(const GemmArgs &g, hipStream_t st);
 int gemm_nt_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st);
 // fused LSTM step for both directions (see GemmArgs::lstm_H)
 int lstm_step_pair(const GemmArgs &g0, const GemmArgs &g1, hipStream_t st);
+// all T fused steps of both directions in ONE launch (gemm.hip: lstm_steps_mfma_kernel).  g0 / g1 = the step-invariant
+// arguments (W2 / ldw2 / lda2 / biases / Cin + ldc = the projection table / M = rows / lstm_H / lstm_ldh / lstm_mcount for the
+// reverse direction); hbuf / cbuf = three rotating state buffers (buffer 0 zeroed; the final state is in buffer T % 3);
+// sync = lstm_steps_sync_words() zeroed words (word 8 = the error word: non-zero when the launch gave up).
+bool lstm_steps_supported(int64_t R, int H);
+size_t lstm_steps_sync_words(int64_t R, int T);
+int lstm_steps_run(const GemmArgs &g0, const GemmArgs &g1, float *const hbuf[3], float *const cbuf[3], const int *tokidx, const int *mcount,
+                   unsigned *sync, int T, hipStream_t st);
 // two GEMMs of identical shape, each cut into nsplit equal K ranges, as ONE grid of 32-row tiles: range j of problem d writes
 // its partial chains to out_d + j * out_stride (the consumer adds the partials in the order 0..nsplit-1).  For the skinny
 // products of backpropagation through time (dh = dpre W_hh: [B,4H] x [4H,H], B a few hundred) whose own grid is 64 workgroups.
