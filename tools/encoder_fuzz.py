@@ -66,9 +66,14 @@ for it in range(iters):
     Wfc = (rs.randn(Dq, 2 * H) * 0.2).astype(np.float32); bfc = rs.randn(Dq).astype(np.float32)
     lt = (rs.rand(vocab, 1).astype(np.float32) + 0.5) if rs.randint(2) else None
     want = oracle.bilstm_final(tokens, emb, lstm, Wfc, bfc, lt)
-    got = _vfr.bilstm_final(d(tokens), d(emb), {k: d(v) for k, v in lstm.items()}, d(Wfc), d(bfc),
-                            d(lt) if lt is not None else None).cpu().numpy()
-    report("bilstm", f"B={B} T={T} E={E} H={H} vocab={vocab} D={Dq} normlen={lt is not None}", np.array_equal(got, want))
+    multi = int(rs.randint(2))                             # the multi-step launch (experiment; taken where the shape qualifies)
+    _vfr.set_option("lstm_multi", multi)
+    try:
+        got = _vfr.bilstm_final(d(tokens), d(emb), {k: d(v) for k, v in lstm.items()}, d(Wfc), d(bfc),
+                                d(lt) if lt is not None else None).cpu().numpy()
+    finally:
+        _vfr.set_option("lstm_multi", 0)
+    report("bilstm", f"B={B} T={T} E={E} H={H} vocab={vocab} D={Dq} normlen={lt is not None} lstm_multi={multi}", np.array_equal(got, want))
 
     # ---- BiLSTM at the model's width (E = 100, H = 1000), 1 .. 34 queries: the single-launch sequence kernels (vector chains for
     # one or two queries, the matrix pipe for 3 .. 32) and the tile steps just above them
