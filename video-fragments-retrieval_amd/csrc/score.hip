@@ -1180,9 +1180,15 @@ static int kpl_for(int k) { return k <= 128 ? 4 : 8; }
 //            videos, which admits only ~8k candidates per query in ...
 //   stage C  ... the rest of the corpus (the main launch); the final merge takes B's merged list as its `extra` input.
 // Every video's full moment set is scored exactly once (stage A's partial pass over 64 videos is the only repeated work).
-constexpr int PRE_VIDEOS = 64;
+#ifndef VFR_PRE_VIDEOS
+#define VFR_PRE_VIDEOS 64
+#endif
+#ifndef VFR_PRE_LEVELS
+#define VFR_PRE_LEVELS 2
+#endif
+constexpr int PRE_VIDEOS = VFR_PRE_VIDEOS;
 constexpr int PRE_CHUNKS = 64;
-constexpr int PRE_LEVELS = 2;       // stage A keeps moments of at most this many clips
+constexpr int PRE_LEVELS = VFR_PRE_LEVELS;       // stage A keeps moments of at most this many clips
 static int pre_b_videos(int Nv) { if (opt_score_pre_b() > 0) return opt_score_pre_b() < Nv ? opt_score_pre_b() : Nv; const int b = Nv / 16; return b > 640 ? 640 : b; }
 
 struct TopkWs { unsigned long long *buf, *buf_pre, *pre_keys, *pre_keys2; int *cnt, *cnt_pre; unsigned long long *thr; size_t total; };
