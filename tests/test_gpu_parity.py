@@ -559,10 +559,20 @@ def test_few_queries_scoring_path(vfr, oracle, nq):
                 vfr.set_option("score_smallq", 64)
                 vfr.set_option("score_smallq_select", 0)       # the key array + selection tree instead of the video selection
                 d3, i3, c3 = vfr.score_topk(Q, bank, k, rd, ri, mode="mfma")
+                vfr.set_option("score_smallq_select", 1)
+                # rank counts with lane = video (`score_smallq_rank`: from 8 queries on by default) forced on at any query count, and off
+                vfr.set_option("score_smallq_rank", 1)
+                d4, i4, c4 = vfr.score_topk(Q, bank, k, rd, ri, mode="mfma")
+                vfr.set_option("score_smallq_rank", 0)
+                d5, i5, c5 = vfr.score_topk(Q, bank, k, rd, ri, mode="mfma")
             finally:
                 vfr.set_option("score_smallq", 64)
                 vfr.set_option("score_smallq_select", 1)
+                vfr.set_option("score_smallq_rank", 8)
             assert c.tolist() == [[p] * nq for p in pos] and torch.equal(c, c2) and torch.equal(c, c3)
+            assert torch.equal(c, c4) and torch.equal(c, c5)
+            if k:
+                assert torch.equal(i, i4) and torch.equal(d, d4) and torch.equal(i, i5) and torch.equal(d, d5)
             if k:
                 # the CPU oracle on the same inputs (the production dispatch for 1-64 queries answered `d, i, c`)
                 assert vfr.get_option("score_smallq") == 64 and vfr.get_option("score_smallq_select") == 1

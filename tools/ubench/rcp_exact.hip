@@ -1,5 +1,6 @@
 // Exhaustive proof-by-enumeration for the cheaper forms in csrc/vfr_math.h (gfx950):
 //   1. c_rcp_ge1(d) == 1.0f / d (hipcc's correctly rounded IEEE division) for EVERY float d in [1, 2^120);
+//   1b. c_div_small(x, L) == x / (float)L for EVERY float x in [2^-60, 2^100] and L = 1 .. 21;
 //   2. c_expf, c_sigmoidf, c_tanhf == their plain restatements (the oracle's text: power of two built from bits, IEEE divisions,
 //      clamp of the negated argument) for EVERY one of the 2^32 float arguments, NaNs compared by class.
 // build + run on the GPU box:  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -I video-fragments-retrieval_amd/csrc
@@ -43,7 +44,7 @@ __device__ __forceinline__ bool same(float a, float b)
     return (na && nb) || (!na && !nb && __float_as_uint(a) == __float_as_uint(b));
 }
 
-// what: 0 = rcp over bit patterns [lo, hi); 1 / 2 / 3 = exp / sigmoid / tanh over [lo, hi)
+// what: 0 = rcp over bit patterns [lo, hi); 1 / 2 / 3 = exp / sigmoid / tanh over [lo, hi); 4 = x / L, L = 1 .. 21
 __global__ void check(int what, unsigned long long lo, unsigned long long hi, unsigned long long *bad, unsigned *first)
 {
     unsigned long long n = 0;
@@ -53,7 +54,12 @@ __global__ void check(int what, unsigned long long lo, unsigned long long hi, un
         if (what == 0) ok = same(vfr::c_rcp_ge1(x), 1.0f / x) && same(2.0f * vfr::c_rcp_ge1(x), 2.0f / x);
         else if (what == 1) ok = same(vfr::c_expf(x), ref::expf_(x));
         else if (what == 2) ok = same(vfr::c_sigmoidf(x), ref::sigmoidf_(x));
-        else ok = same(vfr::c_tanhf(x), ref::tanhf_(x));
+        else if (what == 3) ok = same(vfr::c_tanhf(x), ref::tanhf_(x));
+        else {
+            ok = true;
+#pragma unroll
+            for (int L = 1; L <= 21; ++L) ok = ok && same(vfr::c_div_small(x, L), x / (float)L);
+        }
         if (!ok) { if (n == 0) atomicMin(first, (unsigned)b); ++n; }
     }
     if (n) atomicAdd(bad, n);
@@ -63,10 +69,12 @@ int main()
 {
     unsigned long long *bad; unsigned *first;
     hipMalloc(&bad, 8); hipMalloc(&first, 4);
-    const char *names[4] = {"1/d and 2/d, d in [1, 2^120)", "c_expf, all 2^32 arguments", "c_sigmoidf, all 2^32 arguments", "c_tanhf, all 2^32 arguments"};
+    const char *names[5] = {"1/d and 2/d, d in [1, 2^120)", "c_expf, all 2^32 arguments", "c_sigmoidf, all 2^32 arguments", "c_tanhf, all 2^32 arguments",
+                            "x / L, x in [2^-60, 2^100], L 1..21"};
     int rc = 0;
-    for (int what = 0; what < 4; ++what) {
-        const unsigned long long lo = what == 0 ? 0x3F800000ull : 0ull, hi = what == 0 ? 0x7B800000ull : (1ull << 32);
+    for (int what = 0; what < 5; ++what) {
+        // (2^-60 = 0x21800000, 2^100 = 0x71800000: the range is closed, hence + 1)
+        const unsigned long long lo = what == 0 ? 0x3F800000ull : what == 4 ? 0x21800000ull : 0ull, hi = what == 0 ? 0x7B800000ull : what == 4 ? 0x71800001ull : (1ull << 32);
         unsigned long long z = 0; unsigned f = 0xFFFFFFFFu;
         hipMemcpy(bad, &z, 8, hipMemcpyHostToDevice); hipMemcpy(first, &f, 4, hipMemcpyHostToDevice);
         hipLaunchKernelGGL(check, dim3(4096), dim3(256), 0, 0, what, lo, hi, bad, first);

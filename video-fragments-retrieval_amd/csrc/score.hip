@@ -1574,6 +1574,11 @@ __global__ __launch_bounds__(256) void smallq_dist_kernel(const float *__restric
     // D = 100 (the model's embedding width; other widths take the general loop below): the lane's whole row is requested at
     // once (25 loads in flight), the queries sit in LDS and are read as broadcasts
     __shared__ __attribute__((aligned(16))) float qs[NQ][FAST_D];
+    // blockIdx.y = group of NQ queries: all groups of a request in ONE launch (eight launches of 27 us each were 12 us of
+    // arithmetic and 15 of launch gap, ramp and a 3.2-blocks-per-CU round each)
+    Q += (int64_t)blockIdx.y * NQ * D;
+    dist += (int64_t)blockIdx.y * NQ * total_clips;
+    Nq = Nq - (int)blockIdx.y * NQ < NQ ? Nq - (int)blockIdx.y * NQ : NQ;
     const int c = blockIdx.x * 256 + threadIdx.x;
     float acc[NQ];
 #pragma unroll
@@ -1671,6 +1676,84 @@ __global__ __launch_bounds__(256) void smallq_moments_kernel(const float *__rest
         const int r = threadIdx.x;
         const long long t = (long long)red[r][0] + red[r][1] + red[r][2] + red[r][3];
         if (t) atomicAdd(reinterpret_cast<unsigned long long *>(count_lt + (int64_t)r * Nq + q), (unsigned long long)t);
+    }
+}
+
+// Rank counts + per-video smallest clip distance for the video-selection form (no key array wanted): lane = VIDEO.  The moment
+// kernel above gives a video to 16 threads by start clip -- thread 0 of a 21-clip video walks 26 moments, thread 15 six, and every
+// moment pays an LDS key store, four 64-bit compares, a run-time moment index and an 11-instruction IEEE division: 0.32 ms at 64
+// queries x 10 000 videos, a quarter of that request.  Here a lane keeps its video's distances in registers (+inf past its clip
+// count: such moments compare false), the triangle is straight-line code -- the canonical sum (clips left to right from the start
+// clip), the quotient by a compile-time length as c_div_small (3 instructions, the IEEE quotient for every sum in [2^-60, 2^100]:
+// vfr_math.h), two float compares per rank key -- and the moment id only exists on the slow path: a lane whose score EQUALS a rank
+// distance somewhere (the id decides), or whose distances leave that range, redoes its video with keys and IEEE divisions.
+// One wave per 64 videos and query; from `score_smallq_rank` (8) queries on -- below, the 16-threads-per-video form has more waves
+// in flight for the same work and finishes sooner.
+template <int NT, int NR>
+__global__ __launch_bounds__(64) void smallq_rank_kernel(const float *__restrict__ dist, int Nq, const int32_t *__restrict__ clip_off,
+                                                         const int64_t *__restrict__ mom_off, int Nv, int total_clips, int64_t id_base,
+                                                         int num_rank, const float *__restrict__ rank_dist, const int64_t *__restrict__ rank_idx,
+                                                         int64_t *__restrict__ count_lt, float *__restrict__ dmin)
+{
+    const int q = blockIdx.y, lane = threadIdx.x;
+    const int v = blockIdx.x * 64 + lane;
+    int n = 0, c0 = 0;
+    if (v < Nv) { c0 = clip_off[v]; n = clip_off[v + 1] - c0; }
+    float d[NT];
+    float dm = __builtin_inff(), dx = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const float x = c < n ? dist[(int64_t)q * total_clips + c0 + c] : 0.0f;
+        dm = c < n && x < dm ? x : dm;
+        dx = x > dx ? x : dx;
+        d[c] = c < n ? x : __builtin_inff();
+    }
+    if (dmin && v < Nv) dmin[(int64_t)q * Nv + v] = dm;
+    if (num_rank == 0) return;
+    float kd[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) kd[r] = r < num_rank ? rank_dist[(int64_t)r * Nq + q] : -1.0f;     // (scores are >= 0: an unused key counts nothing)
+    int nlt[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) nlt[r] = 0;
+    // every sum of this video lies in [smallest distance, NT x largest]: inside c_div_small's range?
+    bool slow = n > 0 && (dm < C_DIV_SMALL_LO || dx > C_DIV_SMALL_HI / 32.0f);
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+        float sum = d[s];
+#pragma unroll
+        for (int e = s; e < NT; ++e) {
+            if (e > s) sum = sum + d[e];
+            const float sc = c_div_small(sum, e - s + 1);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                nlt[r] += sc < kd[r] ? 1 : 0;
+                slow = slow || sc == kd[r];
+            }
+        }
+    }
+    if (slow) {
+        unsigned long long kstar[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { nlt[r] = 0; kstar[r] = r < num_rank ? make_key(kd[r], (unsigned)rank_idx[(int64_t)r * Nq + q]) : 0ull; }
+        const int64_t m0 = mom_off[v < Nv ? v : 0];
+        for (int s = 0; s < n; ++s) {
+            float sum = 0.0f;
+            for (int e = s; e < n; ++e) {
+                const float de = dist[(int64_t)q * total_clips + c0 + e];
+                sum = e == s ? de : sum + de;
+                const unsigned long long key = make_key(sum / (float)(e - s + 1), (unsigned)(id_base + m0 + moment_index(n, s, e)));
+#pragma unroll
+                for (int r = 0; r < NR; ++r) nlt[r] += key < kstar[r] ? 1 : 0;
+            }
+        }
+    }
+    for (int r = 0; r < NR; ++r) {
+        if (r >= num_rank) break;
+        int x = nlt[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        if (lane == 0 && x) atomicAdd(reinterpret_cast<unsigned long long *>(count_lt + (int64_t)r * Nq + q), (unsigned long long)x);
     }
 }
 
@@ -1950,7 +2033,7 @@ static bool smallq_applicable(int64_t Nq, int Nv, int total_clips, int max_clips
     return Nq > 0 && Nq <= lim && Nv > 0 && total_clips > 0 && max_clips <= SMALLQ_CLIPS && num_rank <= MAX_RANK && k <= 448;
 }
 static int run_smallq(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets, const int64_t *moment_offsets, int Nv,
-                      int total_clips, int D, float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
+                      int total_clips, int max_clips, int D, float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
                       const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, void *workspace, vfr_stream_t stream);
 
 }  // namespace vfr
@@ -1993,7 +2076,7 @@ int vfr_score_topk_mfma(const float *Q, int64_t Nq, const float *V, const int32_
         VFR_REQUIRE(num_rank == 0 || (rank_dist && rank_idx && count_lt), VFR_EINVAL,
                     "vfr_score_topk_mfma: num_rank > 0 needs rank_dist, rank_idx and count_lt");
         VFR_REQUIRE(id_base >= 0 && D > 0, VFR_EINVAL, "vfr_score_topk_mfma: bad id_base / D");
-        return vfr::run_smallq(Q, Nq, V, clip_offsets, moment_offsets, Nv, total_clips, D, eps, id_base, k, out_dist, out_idx, num_rank,
+        return vfr::run_smallq(Q, Nq, V, clip_offsets, moment_offsets, Nv, total_clips, max_clips, D, eps, id_base, k, out_dist, out_idx, num_rank,
                                rank_dist, rank_idx, count_lt, workspace, stream);
     }
     if (!(Q && V && clip_offsets && moment_offsets && Nq > 0 && k >= 0 && num_rank >= 0) ||
@@ -2331,7 +2414,7 @@ __global__ __launch_bounds__(64) void mfma_selfcheck_kernel(const float *__restr
     if (bad) atomicAdd(mismatches, bad);
 }
 static int run_smallq(const float *Q, int64_t Nq, const float *V, const int32_t *clip_offsets, const int64_t *moment_offsets, int Nv,
-                      int total_clips, int D, float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
+                      int total_clips, int max_clips, int D, float eps, int64_t id_base, int k, float *out_dist, int64_t *out_idx, int num_rank,
                       const float *rank_dist, const int64_t *rank_idx, int64_t *count_lt, void *workspace, vfr_stream_t stream)
 {
     hipStream_t st = as_stream(stream);
@@ -2342,20 +2425,27 @@ static int run_smallq(const float *Q, int64_t Nq, const float *V, const int32_t 
         // eight queries per pass over the bank (sixteen were measured: 0.574 against 0.542 ms at 64 queries, 0.194 against 0.184 at
         // 16 -- the kernel is bound by its 3 VALU issues per (query, clip, dimension), not by the row reads, and the wider
         // form's registers cost a wave of occupancy)
-        for (int64_t q0 = 0; q0 < Nq; q0 += 8) {
-            const int nq = (int)(Nq - q0 < 8 ? Nq - q0 : 8);
-            const float *Qp = Q + q0 * D;
-            float *dp = w.dist + q0 * total_clips;
-            if (nq == 1)      hipLaunchKernelGGL(smallq_dist_kernel<1>, grid, dim3(256), 0, st, Qp, nq, V, total_clips, D, eps, dp);
-            else if (nq == 2) hipLaunchKernelGGL(smallq_dist_kernel<2>, grid, dim3(256), 0, st, Qp, nq, V, total_clips, D, eps, dp);
-            else if (nq <= 4) hipLaunchKernelGGL(smallq_dist_kernel<4>, grid, dim3(256), 0, st, Qp, nq, V, total_clips, D, eps, dp);
-            else              hipLaunchKernelGGL(smallq_dist_kernel<8>, grid, dim3(256), 0, st, Qp, nq, V, total_clips, D, eps, dp);
+        {
+            const dim3 g8(grid.x, (unsigned)cdiv(Nq, 8));
+            if (Nq == 1)      hipLaunchKernelGGL(smallq_dist_kernel<1>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
+            else if (Nq == 2) hipLaunchKernelGGL(smallq_dist_kernel<2>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
+            else if (Nq <= 4) hipLaunchKernelGGL(smallq_dist_kernel<4>, grid, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
+            else              hipLaunchKernelGGL(smallq_dist_kernel<8>, g8, dim3(256), 0, st, Q, (int)Nq, V, total_clips, D, eps, w.dist);
         }
         // top-k by video selection (smallq_select_kernel) unless switched off: then the key array + selection tree
         const bool select = k > 0 && opt_score_smallq_select();
         // unwritten key slots (the padding past the last moment) must read as empty: any value >= KEY_EMPTY does
         if (k > 0 && !select && hipMemsetAsync(w.keys, 0xFF, (size_t)Nq * w.Mpad * 8, st) != hipSuccess)
             return fail(VFR_EHIP, "vfr_score_topk_mfma: hipMemsetAsync failed");
+        if (select && opt_score_smallq_rank() > 0 && Nq >= opt_score_smallq_rank()) {
+            // video-selection form: no key array -- rank counts and the per-video smallest distance with lane = video
+            const dim3 rgrid((unsigned)cdiv(Nv, 64), (unsigned)Nq);
+#define VFR_SQR(NTV, NRV) hipLaunchKernelGGL((smallq_rank_kernel<NTV, NRV>), rgrid, dim3(64), 0, st, w.dist, (int)Nq, clip_offsets, moment_offsets, Nv, total_clips, \
+                                             id_base, num_rank, rank_dist, rank_idx, count_lt, w.dmin)
+            if (max_clips <= 6) { if (num_rank <= 2) VFR_SQR(6, 2); else VFR_SQR(6, MAX_RANK); }
+            else                { if (num_rank <= 2) VFR_SQR(SMALLQ_CLIPS_MAX, 2); else VFR_SQR(SMALLQ_CLIPS_MAX, MAX_RANK); }
+#undef VFR_SQR
+        } else
         if (k > 0 || num_rank > 0)
             hipLaunchKernelGGL(smallq_moments_kernel, dim3((unsigned)cdiv(Nv, SQ_VIDEOS), (unsigned)Nq), dim3(256), 0, st, w.dist, (int)Nq, clip_offsets,
                                moment_offsets, Nv, total_clips, id_base, (k > 0 && !select) ? w.keys : nullptr, w.Mpad, num_rank, rank_dist, rank_idx,

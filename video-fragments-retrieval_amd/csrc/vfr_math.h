@@ -87,6 +87,21 @@ __device__ __forceinline__ float c_tanhf(float x)
 
 #endif
 
+// x / L for a small integer L known at compile time (a moment's length, 1 .. 21): the product with RN(1 / L), one exact
+// residual, one correction -- 3 instructions against the 11 of the compiler's scaled IEEE division, and the CORRECTLY ROUNDED
+// quotient for every float x in [2^-60, 2^100] and every L in 1 .. 21 (enumerated on gfx950: tools/ubench/rcp_exact.hip,
+// profiles/r4_rcp_exact.txt).  Callers keep x inside that range (or take the IEEE division).
+__device__ __forceinline__ float c_div_small(float x, int L)
+{
+    const float fl = (float)L, rl = 1.0f / fl;
+    if ((L & (L - 1)) == 0) return x * rl;                 // a power of two: exact
+    const float q0 = x * rl;
+    const float r = __builtin_fmaf(-fl, q0, x);
+    return __builtin_fmaf(r, rl, q0);
+}
+constexpr float C_DIV_SMALL_LO = 8.673617379884035e-19f;   // 2^-60
+constexpr float C_DIV_SMALL_HI = 1.2676506002282294e30f;   // 2^100
+
 // order-preserving key of a non-negative fp32 distance and a 32-bit moment id
 __device__ __forceinline__ unsigned long long make_key(float d, unsigned id)
 {
