@@ -342,6 +342,7 @@ int vfr_math_f32(int op, const float *x, const float *y, float *out, int64_t n, 
  * "lstm_multi" 0|1 (EXPERIMENT, default 0: one launch per LSTM step | all T steps of both directions in one launch -- ordered task
  * lists per XCD group, completion counters, agent-scope state traffic; with "lstm_tile" 2: 128-row tiles; a give-up is repaired by a
  * rescue kernel and reported through the fault word like the sequence kernels'),
+ * "score_kth_seed" 1|0 (stage A of the top-k threshold ladder takes its seed by bisection on the candidates' score bits | by the merge kernel),
  * "score_smallq_rank" N (few-queries path with video selection: from N queries on -- default 8 -- the rank counts run with lane = video,
  * straight-line triangle, 3-instruction exact quotient; 0: always the 16-threads-per-video moment kernel),
  * "score_defer" N (vfr_score_topk_mfma, f32: whole-video early-out of the rank half of the moment triangle when at most N lanes of

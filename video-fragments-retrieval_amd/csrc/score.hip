@@ -923,6 +923,48 @@ __global__ __launch_bounds__(256) void topk_merge_tasks_kernel(const unsigned lo
     }
 }
 
+// Stage A of the threshold ladder only wants ONE number per query from its candidates: a key that at least k of them do not
+// exceed.  The merge kernel above sorts for it (2 600 candidates per query through 256-key bitonic sorts: 0.20 ms at 5 000
+// queries, three times the stage's scoring kernel).  Here a wave (= a query) holds the score bits of all its candidates in
+// registers -- lane = task, up to KTH_SLOTS per lane -- and finds the k-th smallest SCORE by bisection on the 32 bits: one
+// compare-and-count per candidate and bit, a wave sum, no sort, no LDS.  The seed written is (that score + 1 ulp, id 0): every
+// key of that score passes whatever its id -- as valid a bound as the merge's exact k-th key + 1, looser only among exact ties.
+constexpr int KTH_SLOTS = 44;
+__global__ __launch_bounds__(256) void topk_kth_seed_kernel(const unsigned long long *__restrict__ buf, const int *__restrict__ buf_cnt,
+                                                            int num_groups, int num_chunks, int64_t Nq, int k, int cap_t,
+                                                            unsigned long long *__restrict__ thr_seed, const int *__restrict__ group_mask)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wv;
+    if (q >= Nq) return;
+    const int group = (int)(q >> 6), ql = (int)(q & 63);
+    if (group_mask && !group_mask[group]) return;
+    const int c = lane < num_chunks ? buf_cnt[((size_t)lane * num_groups + group) * 64 + ql] : 0;
+    const int cnt = c < KTH_SLOTS ? c : KTH_SLOTS;                        // (the host only comes here when no column can hold more)
+    unsigned sb[KTH_SLOTS];
+    const unsigned long long *col = buf + (((size_t)lane * num_groups + group) * cap_t) * 64 + ql;
+#pragma unroll
+    for (int i = 0; i < KTH_SLOTS; ++i) sb[i] = i < cnt ? (unsigned)(col[(size_t)i * 64] >> 32) : 0xFFFFFFFFu;
+    int total = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+    if (total < k) return;                                                // fewer than k candidates: no bound from them
+    unsigned lo = 0u, hi = 0xFFFFFFFEu;                                   // smallest t with #(score bits <= t) >= k
+    while (lo < hi) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < KTH_SLOTS; ++i) n += sb[i] <= mid ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+        if (n >= k) hi = mid; else lo = mid + 1u;
+    }
+    if (lane == 0) {
+        const unsigned long long t = ((unsigned long long)lo + 1ull) << 32;
+        if (t < thr_seed[q]) thr_seed[q] = t;
+    }
+}
+
 // merge G shard lists [G, Nq, k] -> [Nq, k] (after the all-gather, 8e).  Lists arrive either as (dist, idx) arrays or as
 // the packed int64 keys the ranks exchange (KEY_EMPTY = (+inf, 0xffffffff) marks an unused slot).  Same LDS pool as the
 // task merge: all G*k keys are read as one flat sequence, CAP per round with the loads in flight together, and a key is
@@ -1369,7 +1411,12 @@ static int run_pass(ScoreArgs a, const TopkWs &w, bool seeded, float *out_dist, 
             if (int rc = launch_score<1>(pre, kpl, st, &cap_pre)) return rc;
             {
                 ProfScope prof(SITE_TOPK_MERGE, st);
-                merge(w.buf_pre, w.cnt_pre, na, cap_pre, nullptr, nullptr, w.thr, nullptr, nullptr, 1);
+                // (a column of stage A holds at most PRE_LEVELS x clips-per-video keys: the bisection kernel when they fit its registers)
+                if (opt_score_kth_seed() && cap_pre > 0 && na <= 64 && PRE_LEVELS * a.ds_rows <= KTH_SLOTS)
+                    hipLaunchKernelGGL(topk_kth_seed_kernel, dim3((unsigned)cdiv(Nq, 4)), dim3(256), 0, st, w.buf_pre, w.cnt_pre, a.num_groups, na, Nq, k,
+                                       cap_pre, w.thr, a.group_mask);
+                else
+                    merge(w.buf_pre, w.cnt_pre, na, cap_pre, nullptr, nullptr, w.thr, nullptr, nullptr, 1);
             }
             VFR_CHECK_LAUNCH("topk_merge_tasks_kernel(A)");
         }

@@ -33,6 +33,7 @@ static std::atomic<int> g_opt_lstm_persist_max{32}; // ... and up to this many. 
 static std::atomic<int> g_opt_lstm_multi{0};       // EXPERIMENT (off): 1 = all T steps of the fused BiLSTM in ONE launch (gemm.hip: lstm_steps_mfma_kernel; 128-row tiles with lstm_tile 2) -- same bits; measured no faster than one launch per step at 5 000 queries, 4-5 % faster around 2 500 (HISTORY.md)
 static std::atomic<int> g_opt_lstm_fast{1};        // 1: the table-start LSTM step without selects in its K-loop where the launch qualifies; 0: always the general form (cross-check)
 static std::atomic<int> g_opt_smallq_rank{8};       // N: few-queries path, video-selection form, from N queries on: rank counts with lane = video (smallq_rank_kernel); 0: always the moment kernel (cross-check)
+static std::atomic<int> g_opt_kth_seed{1};          // 1: stage A of the top-k threshold ladder takes its seed by bisection on the score bits (topk_kth_seed_kernel); 0: by the merge kernel (cross-check)
 static std::atomic<int> g_opt_vgg_halo{1};         // 1: the VGG stack on halo-padded activations where its shape allows (select-free convolution loader); 0: unpadded (cross-check)
 static std::atomic<int> g_opt_lstm_small4{1};      // 1: a single query of the model's shape takes the four-wave vector-chain step (weights streamed by three loader waves); 0: the one-wave step (cross-check)
 static std::atomic<int> g_opt_score_defer{8};      // MFMA pre-filter, whole-video early-out: skip the rank half of the moment triangle when at most this many lanes of a wave are left undecided by dmin / dmax (they are re-counted exactly); -1: off (cross-check)
@@ -44,7 +45,7 @@ struct Opt { const char *name; std::atomic<int> *v; };
 static const Opt g_opts[] = {
     {"gemm", &g_opt_gemm}, {"profile", &g_opt_profile}, {"score_fast", &g_opt_score_fast}, {"score_split", &g_opt_score_split},
     {"score_pre_b", &g_opt_score_pre_b}, {"score_smallq", &g_opt_score_smallq}, {"score_tasks", &g_opt_score_tasks}, {"lstm_skip0", &g_opt_lstm_skip0},
-    {"lstm_xcd", &g_opt_lstm_xcd}, {"gemm_small", &g_opt_gemm_small}, {"lstm_tile", &g_opt_lstm_tile}, {"lstm_small4", &g_opt_lstm_small4}, {"lstm_persist", &g_opt_lstm_persist}, {"lstm_persist_min", &g_opt_lstm_persist_min}, {"lstm_fast", &g_opt_lstm_fast}, {"lstm_multi", &g_opt_lstm_multi}, {"lstm_persist_max", &g_opt_lstm_persist_max}, {"lstm_persist_fault", &g_opt_lstm_persist_fault}, {"vgg_fuse_pool", &g_opt_vgg_fuse_pool}, {"vgg_direct1", &g_opt_vgg_direct1}, {"vgg_halo", &g_opt_vgg_halo}, {"score_smallq_rank", &g_opt_smallq_rank}, {"score_smallq_select", &g_opt_smallq_select}, {"gemm_pp", &g_opt_gemm_pp}, {"score_mfma_min", &g_opt_mfma_min}, {"lstm_small", &g_opt_lstm_small}, {"score_defer", &g_opt_score_defer}, {"score_sort", &g_opt_score_sort}, {"score_hist", &g_opt_score_hist},
+    {"lstm_xcd", &g_opt_lstm_xcd}, {"gemm_small", &g_opt_gemm_small}, {"lstm_tile", &g_opt_lstm_tile}, {"lstm_small4", &g_opt_lstm_small4}, {"lstm_persist", &g_opt_lstm_persist}, {"lstm_persist_min", &g_opt_lstm_persist_min}, {"lstm_fast", &g_opt_lstm_fast}, {"lstm_multi", &g_opt_lstm_multi}, {"lstm_persist_max", &g_opt_lstm_persist_max}, {"lstm_persist_fault", &g_opt_lstm_persist_fault}, {"vgg_fuse_pool", &g_opt_vgg_fuse_pool}, {"vgg_direct1", &g_opt_vgg_direct1}, {"vgg_halo", &g_opt_vgg_halo}, {"score_kth_seed", &g_opt_kth_seed}, {"score_smallq_rank", &g_opt_smallq_rank}, {"score_smallq_select", &g_opt_smallq_select}, {"gemm_pp", &g_opt_gemm_pp}, {"score_mfma_min", &g_opt_mfma_min}, {"lstm_small", &g_opt_lstm_small}, {"score_defer", &g_opt_score_defer}, {"score_sort", &g_opt_score_sort}, {"score_hist", &g_opt_score_hist},
 };
 
 struct ProfPair { int site; hipEvent_t a, b; };
@@ -110,6 +111,7 @@ int opt_lstm_persist_fault() { return g_opt_lstm_persist_fault; }
 int opt_vgg_fuse_pool() { return g_opt_vgg_fuse_pool; }
 int opt_vgg_direct1() { return g_opt_vgg_direct1; }
 int opt_vgg_halo() { return g_opt_vgg_halo; }
+int opt_score_kth_seed() { return g_opt_kth_seed; }
 int opt_score_smallq_rank() { return g_opt_smallq_rank; }
 int opt_score_smallq_select() { return g_opt_smallq_select; }
 int device_cu_count()

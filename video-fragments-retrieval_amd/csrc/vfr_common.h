@@ -38,6 +38,7 @@ int opt_vgg_fuse_pool();
 int opt_vgg_direct1();
 int opt_vgg_halo();
 int opt_score_smallq_rank();
+int opt_score_kth_seed();
 int device_cu_count();                  // of the CURRENT device (cached per device)
 constexpr int VFR_MAX_DEVICES = 64;     // per-device caches (CU count, kernel attributes)
 unsigned *fault_word();                 // vfr_set_fault_word: device-accessible host word kernels raise fault bits in (nullable)
